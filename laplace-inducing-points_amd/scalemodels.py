@@ -1,0 +1,67 @@
+"""Scale workloads — the nets of ``src/scalemodels.py`` as layer programs.
+
+``LargeClassifier`` (``:52-67``): flatten -> numl x [Dense(numh[j]) -> tanh] -> Dense(numc).
+``ResNet1M`` (``:115-157``) with ``BasicBlock`` (``:70-112``): 3x3 conv(32)+BN+ReLU, then
+3 blocks @32, 3 @64 (first stride 2), 3 @128 (first stride 2), global mean pool, Dense.
+Convs are bias-free 'SAME'; BatchNorm runs in eval mode (running statistics), as the
+GGN code calls ``apply_fn(..., train=False, mutable=False)`` (``src/ggn.py:52,123``).
+Flax auto-names: ``Conv_0, BatchNorm_0, BasicBlock_0..8/{Conv_0,BatchNorm_0,Conv_1,
+BatchNorm_1[,Conv_2,BatchNorm_2]}, Dense_0``.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+from .netspec import NetSpec
+from .utils import TrainState  # noqa: F401  (reference exports TrainState here, :161)
+
+
+def LargeClassifier(input_shape: Sequence[int], numh: Sequence[int], numl: int, numc: int) -> NetSpec:
+    net = NetSpec(tuple(input_shape))
+    t = net.flatten(0)
+    for j in range(numl):
+        t = net.dense(t, f"Dense_{j}", int(numh[j]), act="tanh")
+    net.dense(t, f"Dense_{numl}", numc)
+    net.model_type = "classifier"
+    return net
+
+
+def _basic_block(net: NetSpec, x: int, scope: str, channels: int, stride: int) -> int:
+    sc = (scope,)
+    h = net.conv(x, "Conv_0", channels, 3, stride, bn="BatchNorm_0", act="relu", scope=sc)
+    need_proj = (stride != 1) or (net.tensors[x][2] != channels)
+    if need_proj:
+        # 1x1 projection of the block input (Flax names it Conv_2/BatchNorm_2, :100-108)
+        r = net.conv(x, "Conv_2", channels, 1, stride, bn="BatchNorm_2", act="none", scope=sc)
+        return net.conv(h, "Conv_1", channels, 3, 1, bn="BatchNorm_1", res=r, act="relu", scope=sc)
+    return net.conv(h, "Conv_1", channels, 3, 1, bn="BatchNorm_1", res=x, act="relu", scope=sc)
+
+
+def ResNet1M(num_classes: int, input_shape: Sequence[int] = (32, 32, 3),
+             widths: Sequence[int] = (32, 64, 128), blocks_per_stage: int = 3) -> NetSpec:
+    net = NetSpec(tuple(input_shape))
+    x = net.conv(0, "Conv_0", widths[0], 3, 1, bn="BatchNorm_0", act="relu")
+    b = 0
+    for si, ch in enumerate(widths):
+        for j in range(blocks_per_stage):
+            stride = 2 if (si > 0 and j == 0) else 1
+            x = _basic_block(net, x, f"BasicBlock_{b}", ch, stride)
+            b += 1
+    x = net.meanpool(x)
+    net.dense(x, "Dense_0", num_classes)
+    net.model_type = "classifier"
+    return net
+
+
+def get_model(model_cfg) -> NetSpec:
+    """Reference ``src/scalemodels.py:166-186`` (LeNet5 is not on the hot-path configs)."""
+    name = model_cfg["name"]
+    if name == "large_classifier":
+        return LargeClassifier(tuple(model_cfg["input_shape"]), model_cfg["num_h"],
+                               model_cfg["num_l"], model_cfg.get("num_c"))
+    if name == "classifier":
+        from .toymodels import SimpleClassifier
+        return SimpleClassifier(model_cfg["num_h"], model_cfg["num_l"], model_cfg.get("num_c"))
+    if name == "ResNet1":
+        return ResNet1M(model_cfg.get("num_c"))
+    raise ValueError(f"Unknown model name: {name}")
