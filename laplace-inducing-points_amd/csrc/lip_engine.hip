@@ -1,0 +1,354 @@
+// Op-tape interpreter + C ABI of the linearised-network engine (see include/lip.h).
+//
+// The Python host compiles a NetSpec into three tapes of lip_op_t (primal, tangent-forward,
+// backward).  The engine resolves operand references against the bound device buffers and
+// launches the HIP kernels on the caller's stream, chunking the probe dimension so that the
+// tangent workspace fits the budget the caller allocated.  No allocation, no synchronisation
+// and no host<->device copy happens inside a run (hipGraph-capturable).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "lip_internal.h"
+
+namespace lip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace lip
+
+using namespace lip;
+
+struct lip_engine {
+  int64_t D = 0;
+  int32_t n_img = 0, K = 0;
+  std::vector<lip_op_t> tape[3];
+  const float* theta = nullptr;
+  const float* consts = nullptr;
+  float* prim = nullptr;
+  float* work = nullptr;
+  int64_t work_pp = 0;      // workspace floats per probe
+  int32_t max_chunk = 0;    // probes per chunk
+  bool primal_done = false;
+};
+
+namespace {
+
+struct RunCtx {
+  const lip_engine* e;
+  const float* V;   // chunk-shifted
+  float* Y;
+  float* H;         // HEAD space, chunk-shifted
+  int P;            // probes in this chunk
+  int head_mode;
+  float head_c;
+  hipStream_t st;
+};
+
+inline float* resolve(const RunCtx& c, const lip_ref_t& r) {
+  switch (r.space) {
+    case LIP_SP_THETA: return const_cast<float*>(c.e->theta) + r.off;
+    case LIP_SP_CONST: return const_cast<float*>(c.e->consts) + r.off;
+    case LIP_SP_PRIM: return c.e->prim + r.off;
+    case LIP_SP_WORK: return c.e->work + r.off * (int64_t)c.e->max_chunk;
+    case LIP_SP_VIN: return c.V ? const_cast<float*>(c.V) + r.off : nullptr;
+    case LIP_SP_YOUT: return c.Y ? c.Y + r.off : nullptr;
+    case LIP_SP_HEAD: return c.H ? c.H + r.off : nullptr;
+    default: return nullptr;
+  }
+}
+
+#define RUN_CHECK(expr, what)                                                                  \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(_e)); return LIP_ERR_HIP; } \
+  } while (0)
+
+int check_space(const RunCtx& c, const lip_ref_t& r, const char* what) {
+  if (r.space == LIP_SP_NONE) return LIP_OK;
+  if (resolve(c, r) == nullptr) { set_error("op operand '%s' refers to an unbound space %d", what, r.space); return LIP_ERR_STATE; }
+  return LIP_OK;
+}
+
+int run_op(const RunCtx& c, const lip_op_t& op) {
+  switch (op.kind) {
+    case LIP_OP_IGEMM: {
+      if (op.nseg < 1 || op.nseg > 3) { set_error("IGEMM: nseg=%d", op.nseg); return LIP_ERR_ARG; }
+      IgemmP p;
+      memset(&p, 0, sizeof(p));
+      p.nseg = op.nseg;
+      for (int s = 0; s < op.nseg; ++s) {
+        const lip_seg_t& g = op.seg[s];
+        int rc;
+        if ((rc = check_space(c, g.a, "seg.a")) || (rc = check_space(c, g.b, "seg.b"))) return rc;
+        SegP& q = p.seg[s];
+        q.a = resolve(c, g.a); q.a_ps = g.a.pstride;
+        q.b = resolve(c, g.b); q.b_ps = g.b.pstride;
+        q.IH = g.IH; q.IW = g.IW; q.C = g.C; q.KH = g.KH; q.KW = g.KW;
+        q.stride = g.stride; q.pad_h = g.pad_h; q.pad_w = g.pad_w; q.mode = g.mode;
+        q.Ktot = g.KH * g.KW * g.C;
+        if (!q.a || !q.b || q.Ktot <= 0 || q.stride <= 0) { set_error("IGEMM: bad segment %d", s); return LIP_ERR_ARG; }
+        if ((q.C & 3) == 0 && ((((uintptr_t)q.a) & 15) || (q.a_ps & 3))) { set_error("IGEMM: segment %d activations not 16-byte aligned", s); return LIP_ERR_ARG; }
+      }
+      p.R = op.n_img * op.OH * op.OW; p.OHW = op.OH * op.OW; p.OW = op.OW; p.N = op.N;
+      p.out = resolve(c, op.out); p.out_ps = op.out.pstride;
+      p.scale = resolve(c, op.scale);
+      p.e0 = resolve(c, op.e0); p.e0_ps = op.e0.pstride;
+      p.e1 = resolve(c, op.e1); p.e1_ps = op.e1.pstride;
+      p.xhat = resolve(c, op.xhat);
+      p.res = resolve(c, op.res); p.res_ps = op.res.pstride;
+      p.dphi = resolve(c, op.dphi);
+      p.red0 = resolve(c, op.red0); p.red0_ps = op.red0.pstride;
+      p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
+      p.xhat2 = resolve(c, op.xhat2);
+      if (!p.out || p.R <= 0 || p.N <= 0) { set_error("IGEMM: bad output"); return LIP_ERR_ARG; }
+      if (p.e1 && !p.xhat) { set_error("IGEMM: e1 without xhat"); return LIP_ERR_ARG; }
+      if (p.red1 && !p.xhat2) { set_error("IGEMM: red1 without xhat2"); return LIP_ERR_ARG; }
+      RUN_CHECK(launch_igemm(p, c.P, c.st), "igemm launch");
+      return LIP_OK;
+    }
+    case LIP_OP_WGRAD: {
+      const lip_seg_t& g = op.seg[0];
+      WgradP p;
+      memset(&p, 0, sizeof(p));
+      p.a = resolve(c, g.a);
+      p.IH = g.IH; p.IW = g.IW; p.C = g.C; p.KH = g.KH; p.KW = g.KW;
+      p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
+      p.g = resolve(c, g.b); p.g_ps = g.b.pstride;
+      p.R = op.n_img * op.OH * op.OW; p.OHW = op.OH * op.OW; p.OW = op.OW; p.N = op.N;
+      p.M = g.KH * g.KW * g.C;
+      p.y = resolve(c, op.out); p.y_ps = op.out.pstride;
+      p.scale = resolve(c, op.scale);
+      p.ksplit = op.ksplit > 0 ? op.ksplit : 1;
+      if (op.ksplit <= 0) {
+        // few probes: split the row reduction (float atomics) so the launch still fills 256 CUs
+        const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * c.P;
+        if (tiles < 512) {
+          long long ks = (1024 + tiles - 1) / tiles;
+          const long long maxks = (p.R + 63) / 64;
+          if (ks > maxks) ks = maxks;
+          if (ks > 1024) ks = 1024;
+          p.ksplit = ks < 1 ? 1 : (int)ks;
+        }
+      }
+      if (!p.a || !p.g || !p.y || p.R <= 0 || p.N <= 0 || p.M <= 0) { set_error("WGRAD: bad operands"); return LIP_ERR_ARG; }
+      if ((p.C & 3) == 0 && (((uintptr_t)p.a) & 15)) { set_error("WGRAD: activations not 16-byte aligned"); return LIP_ERR_ARG; }
+      RUN_CHECK(launch_wgrad(p, c.P, c.st), "wgrad launch");
+      return LIP_OK;
+    }
+    case LIP_OP_REDUCE: {
+      ReduceP p;
+      memset(&p, 0, sizeof(p));
+      p.g = resolve(c, op.seg[0].a); p.g_ps = op.seg[0].a.pstride;
+      p.R = op.n_img * op.OH * op.OW; p.N = op.N;
+      p.xhat = resolve(c, op.xhat2);
+      p.red0 = resolve(c, op.red0); p.red0_ps = op.red0.pstride;
+      p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
+      if (!p.g || p.N <= 0 || p.N > 8192 || (p.red1 && !p.xhat)) { set_error("REDUCE: bad operands"); return LIP_ERR_ARG; }
+      RUN_CHECK(launch_reduce(p, c.P, c.st), "reduce launch");
+      return LIP_OK;
+    }
+    case LIP_OP_POOL_FWD:
+    case LIP_OP_POOL_BWD: {
+      PoolP p;
+      memset(&p, 0, sizeof(p));
+      p.in = resolve(c, op.seg[0].a); p.in_ps = op.seg[0].a.pstride;
+      p.out = resolve(c, op.out); p.out_ps = op.out.pstride;
+      p.n = op.n_img; p.HW = op.OH * op.OW; p.C = op.N; p.inv = op.fscale;
+      p.dphi = resolve(c, op.dphi);
+      p.xhat = resolve(c, op.xhat2);
+      p.red0 = resolve(c, op.red0); p.red0_ps = op.red0.pstride;
+      p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
+      if (!p.in || !p.out || p.C <= 0 || p.C > 8192 || (p.red1 && !p.xhat)) { set_error("POOL: bad operands"); return LIP_ERR_ARG; }
+      if (op.kind == LIP_OP_POOL_FWD) RUN_CHECK(launch_pool_fwd(p, c.P, c.st), "pool_fwd launch");
+      else RUN_CHECK(launch_pool_bwd(p, c.P, c.st), "pool_bwd launch");
+      return LIP_OK;
+    }
+    case LIP_OP_PRIMAL_POST: {
+      PrimalPostP p;
+      memset(&p, 0, sizeof(p));
+      p.z = resolve(c, op.seg[0].a);
+      p.a = resolve(c, op.out); p.dphi = resolve(c, op.out2); p.xhat = resolve(c, op.out3);
+      p.bias = resolve(c, op.e0);
+      p.gamma = resolve(c, op.e1); p.beta = resolve(c, op.scale);
+      p.mean = resolve(c, op.aux0); p.rstd = resolve(c, op.aux1);
+      p.res = resolve(c, op.res);
+      p.count = (long long)op.n_img * op.OH * op.OW * op.N; p.N = op.N; p.act = op.act;
+      if (!p.z || !p.a || (p.gamma && (!p.beta || !p.mean || !p.rstd))) { set_error("PRIMAL_POST: bad operands"); return LIP_ERR_ARG; }
+      RUN_CHECK(launch_primal_post(p, c.st), "primal_post launch");
+      return LIP_OK;
+    }
+    case LIP_OP_SOFTMAX: {
+      const float* in = resolve(c, op.seg[0].a);
+      float* pr = resolve(c, op.out); float* sq = resolve(c, op.out2);
+      if (!in || !pr || !sq) { set_error("SOFTMAX: bad operands"); return LIP_ERR_ARG; }
+      RUN_CHECK(launch_softmax(in, pr, sq, op.n_img, op.N, c.st), "softmax launch");
+      return LIP_OK;
+    }
+    case LIP_OP_HEAD: {
+      HeadP p;
+      memset(&p, 0, sizeof(p));
+      p.n = op.n_img; p.K = op.N; p.mode = c.head_mode; p.classifier = op.classifier; p.c = c.head_c;
+      p.p = resolve(c, op.aux0); p.s = resolve(c, op.aux1);
+      const lip_ref_t* in; const lip_ref_t* out;
+      switch (c.head_mode) {
+        case LIP_HEAD_GGN: in = &op.seg[0].a; out = &op.out; break;
+        case LIP_HEAD_LT: case LIP_HEAD_OUT: in = &op.seg[0].a; out = &op.out2; break;
+        case LIP_HEAD_L: case LIP_HEAD_IN: in = &op.out2; out = &op.out; break;
+        default: set_error("HEAD: bad mode %d", c.head_mode); return LIP_ERR_ARG;
+      }
+      p.in = resolve(c, *in); p.in_ps = in->pstride;
+      p.out = resolve(c, *out); p.out_ps = out->pstride;
+      if (!p.in || !p.out || (p.classifier && (!p.p || !p.s))) { set_error("HEAD: bad operands (mode %d)", c.head_mode); return LIP_ERR_ARG; }
+      RUN_CHECK(launch_head(p, c.P, c.st), "head launch");
+      return LIP_OK;
+    }
+    default:
+      set_error("unknown op kind %d", op.kind);
+      return LIP_ERR_ARG;
+  }
+}
+
+int run_tape(const RunCtx& c, int which, bool skip_head) {
+  const std::vector<lip_op_t>& t = c.e->tape[which];
+  if (t.empty()) { set_error("tape %d is empty", which); return LIP_ERR_STATE; }
+  for (size_t i = 0; i < t.size(); ++i) {
+    if (skip_head && t[i].kind == LIP_OP_HEAD) continue;
+    const int rc = run_op(c, t[i]);
+    if (rc != LIP_OK) {
+      char buf[400];
+      snprintf(buf, sizeof(buf), "%s", g_err);
+      set_error("tape %d op %zu (kind %d): %s", which, i, t[i].kind, buf);
+      return rc;
+    }
+  }
+  return LIP_OK;
+}
+
+int ready(const lip_engine* e, const char* who) {
+  if (!e) { set_error("%s: null engine", who); return LIP_ERR_ARG; }
+  if (!e->theta || !e->prim || !e->work || e->max_chunk <= 0) { set_error("%s: engine not bound", who); return LIP_ERR_STATE; }
+  if (!e->primal_done) { set_error("%s: primal pass not run", who); return LIP_ERR_STATE; }
+  return LIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lip_abi_version(void) { return 1; }
+const char* lip_last_error(void) { return g_err; }
+int lip_sizeof_op(void) { return (int)sizeof(lip_op_t); }
+
+int lip_engine_create(lip_engine_t** out, int64_t D, int32_t n_img, int32_t K) {
+  if (!out || D <= 0 || n_img <= 0 || K <= 0) { set_error("lip_engine_create: bad argument"); return LIP_ERR_ARG; }
+  lip_engine* e = new lip_engine();
+  e->D = D; e->n_img = n_img; e->K = K;
+  *out = e;
+  return LIP_OK;
+}
+
+int lip_engine_destroy(lip_engine_t* e) {
+  delete e;
+  return LIP_OK;
+}
+
+int lip_engine_set_tape(lip_engine_t* e, int32_t which, const lip_op_t* ops, int32_t nops) {
+  if (!e || which < 0 || which > 2 || !ops || nops <= 0) { set_error("lip_engine_set_tape: bad argument"); return LIP_ERR_ARG; }
+  e->tape[which].assign(ops, ops + nops);
+  if (which == LIP_TAPE_PRIMAL) e->primal_done = false;
+  return LIP_OK;
+}
+
+int lip_engine_bind(lip_engine_t* e, const float* theta, const float* consts, float* prim, float* work,
+                    int64_t work_floats_per_probe, int32_t max_probes_per_chunk) {
+  if (!e || !theta || !prim || !work || work_floats_per_probe <= 0 || max_probes_per_chunk <= 0) {
+    set_error("lip_engine_bind: bad argument");
+    return LIP_ERR_ARG;
+  }
+  if ((((uintptr_t)prim) & 15) || (((uintptr_t)work) & 15) || (consts && (((uintptr_t)consts) & 15))) {
+    set_error("lip_engine_bind: buffers must be 16-byte aligned");
+    return LIP_ERR_ARG;
+  }
+  e->theta = theta; e->consts = consts; e->prim = prim; e->work = work;
+  e->work_pp = work_floats_per_probe; e->max_chunk = max_probes_per_chunk;
+  e->primal_done = false;
+  return LIP_OK;
+}
+
+int lip_engine_primal(lip_engine_t* e, void* stream) {
+  if (!e || !e->theta || !e->prim) { set_error("lip_engine_primal: engine not bound"); return LIP_ERR_STATE; }
+  RunCtx c{e, nullptr, nullptr, nullptr, 1, 0, 1.f, (hipStream_t)stream};
+  const int rc = run_tape(c, LIP_TAPE_PRIMAL, false);
+  if (rc == LIP_OK) e->primal_done = true;
+  return rc;
+}
+
+int lip_debug_run_ops(lip_engine_t* e, int32_t which, int32_t first, int32_t count, const float* V, float* Y,
+                      float* H, int32_t P, int32_t head_mode, float head_c, void* stream) {
+  if (!e || which < 0 || which > 2 || P <= 0 || P > e->max_chunk) { set_error("lip_debug_run_ops: bad argument"); return LIP_ERR_ARG; }
+  const std::vector<lip_op_t>& t = e->tape[which];
+  if (first < 0 || count < 0 || (size_t)(first + count) > t.size()) { set_error("lip_debug_run_ops: bad op range"); return LIP_ERR_ARG; }
+  RunCtx c{e, V, Y, H, P, head_mode, head_c, (hipStream_t)stream};
+  for (int i = first; i < first + count; ++i) {
+    const int rc = run_op(c, t[i]);
+    if (rc) return rc;
+  }
+  return LIP_OK;
+}
+
+int lip_ggn_vp(lip_engine_t* e, const float* V, float* Y, int32_t P, float scale, float alpha, void* stream) {
+  int rc = ready(e, "lip_ggn_vp");
+  if (rc) return rc;
+  if (!V || !Y || P <= 0) { set_error("lip_ggn_vp: bad argument"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
+    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+    const float* v = V + (int64_t)c0 * e->D;
+    float* y = Y + (int64_t)c0 * e->D;
+    if (alpha != 0.f) RUN_CHECK(launch_scale_copy(y, v, alpha, (long long)pc * e->D, st), "scale_copy");
+    else RUN_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)pc * e->D, st), "memset Y");
+    RunCtx c{e, v, y, nullptr, pc, LIP_HEAD_GGN, scale, st};
+    if ((rc = run_tape(c, LIP_TAPE_TANGENT, false))) return rc;
+    if ((rc = run_tape(c, LIP_TAPE_BACKWARD, true))) return rc;
+  }
+  return LIP_OK;
+}
+
+int lip_jvp(lip_engine_t* e, const float* V, float* U, int32_t P, int32_t head_mode, float cc, void* stream) {
+  int rc = ready(e, "lip_jvp");
+  if (rc) return rc;
+  if (!V || !U || P <= 0 || (head_mode != LIP_HEAD_LT && head_mode != LIP_HEAD_OUT)) { set_error("lip_jvp: bad argument"); return LIP_ERR_ARG; }
+  const int64_t hstride = (int64_t)e->n_img * e->K;
+  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
+    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+    RunCtx c{e, V + (int64_t)c0 * e->D, nullptr, U + (int64_t)c0 * hstride, pc, head_mode, cc, (hipStream_t)stream};
+    if ((rc = run_tape(c, LIP_TAPE_TANGENT, false))) return rc;
+  }
+  return LIP_OK;
+}
+
+int lip_vjp(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_mode, float cc, void* stream) {
+  int rc = ready(e, "lip_vjp");
+  if (rc) return rc;
+  if (!U || !Y || P <= 0 || (head_mode != LIP_HEAD_L && head_mode != LIP_HEAD_IN)) { set_error("lip_vjp: bad argument"); return LIP_ERR_ARG; }
+  const int64_t hstride = (int64_t)e->n_img * e->K;
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
+    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+    float* y = Y + (int64_t)c0 * e->D;
+    RUN_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)pc * e->D, st), "memset Y");
+    RunCtx c{e, nullptr, y, const_cast<float*>(U) + (int64_t)c0 * hstride, pc, head_mode, cc, st};
+    if ((rc = run_tape(c, LIP_TAPE_BACKWARD, false))) return rc;
+  }
+  return LIP_OK;
+}
+
+}  // extern "C"

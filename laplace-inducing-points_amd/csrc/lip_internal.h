@@ -1,0 +1,95 @@
+// Internal (non-ABI) declarations shared by the HIP translation units of liblip_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lip.h"
+
+namespace lip {
+
+// ---- resolved (device-pointer) parameter blocks handed to the kernels -------------------
+struct SegP {
+  const float* a; long long a_ps;
+  const float* b; long long b_ps;
+  int IH, IW, C, KH, KW, stride, pad_h, pad_w, mode, Ktot;
+};
+
+struct IgemmP {
+  int nseg;
+  SegP seg[3];
+  int R, OHW, OW, N;
+  float* out; long long out_ps;
+  const float* scale;
+  const float* e0; long long e0_ps;
+  const float* e1; long long e1_ps;
+  const float* xhat;
+  const float* res; long long res_ps;
+  const float* dphi;
+  float* red0; long long red0_ps;
+  float* red1; long long red1_ps;
+  const float* xhat2;
+};
+
+struct WgradP {
+  const float* a;                       // primal activations [n][IH][IW][C]
+  int IH, IW, C, KH, KW, stride, pad_h, pad_w;
+  const float* g; long long g_ps;       // cotangent [P][R][N]
+  int R, OHW, OW, N, M;                 // M = KH*KW*C
+  float* y; long long y_ps;             // Y + param offset, element [m*N + co]
+  const float* scale;                   // per-channel [N] or null
+  int ksplit;
+};
+
+struct ReduceP {
+  const float* g; long long g_ps; int R, N;
+  const float* xhat;
+  float* red0; long long red0_ps;
+  float* red1; long long red1_ps;
+};
+
+struct PoolP {
+  const float* in; long long in_ps;     // fwd: [P][n][HW][C]   bwd: [P][n][C]
+  float* out; long long out_ps;         // fwd: [P][n][C]       bwd: [P][n][HW][C]
+  int n, HW, C; float inv;
+  const float* dphi;                    // bwd: [n][HW][C] or null
+  const float* xhat;                    // bwd: for red1
+  float* red0; long long red0_ps;
+  float* red1; long long red1_ps;
+};
+
+struct PrimalPostP {
+  const float* z; float* a; float* dphi; float* xhat;   // all [R][N]
+  const float* bias;                    // [N] or null          (THETA)
+  const float* gamma; const float* beta;                 // BN   (THETA) or null
+  const float* mean; const float* rstd;                  // BN   (CONST)
+  const float* res;                     // [R][N] or null
+  long long count; int N; int act;
+};
+
+struct HeadP {
+  const float* in; long long in_ps;     // [P][n][K]
+  float* out; long long out_ps;         // [P][n][K]
+  const float* p; const float* s;       // softmax probs / sqrt [n][K]
+  int n, K, mode, classifier; float c;
+};
+
+// ---- launchers (return hipError_t of the launch) ------------------------------------------
+hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st);
+hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st);
+hipError_t launch_reduce(const ReduceP& p, int P, hipStream_t st);
+hipError_t launch_pool_fwd(const PoolP& p, int P, hipStream_t st);
+hipError_t launch_pool_bwd(const PoolP& p, int P, hipStream_t st);
+hipError_t launch_primal_post(const PrimalPostP& p, hipStream_t st);
+hipError_t launch_softmax(const float* logits, float* prob, float* sqrtp, int n, int K, hipStream_t st);
+hipError_t launch_head(const HeadP& p, int P, hipStream_t st);
+hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st);
+
+void set_error(const char* fmt, ...);
+
+// ---- wave / block reductions (wave = 64 lanes on gfx950) --------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace lip

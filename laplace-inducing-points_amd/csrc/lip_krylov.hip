@@ -1,0 +1,383 @@
+// Krylov / trace primitives on blocks of vectors X (P, N) row-major — HBM-bound kernels:
+// 16-byte loads where the row alignment allows (rows of an odd-length D-vector block are not
+// 16-byte aligned, so every row is split into scalar head | float4 body | scalar tail),
+// per-wave shuffle reductions, one float atomic per wave/block.
+//
+// Replaces what XLA emits for matfree's Lanczos (reference src/sample.py:114-126), JAX's CG
+// (src/stochtrace.py:146,192; src/sample.py:71) and the Hutchinson quadratic forms
+// (src/stochtrace.py:30-34).
+#include <stdarg.h>
+#include <stdio.h>
+#include "lip_internal.h"
+
+namespace lip {
+
+constexpr int KT = 256;        // threads per block
+constexpr int CHUNK = KT * 8;  // elements of one row handled by one block
+
+struct RowSplit { long long h, G; };   // head length, number of aligned quads
+
+__device__ __forceinline__ RowSplit split_row(const float* x, long long N) {
+  RowSplit s;
+  const long long mis = ((unsigned long long)x >> 2) & 3;
+  s.h = (4 - mis) & 3;
+  if (s.h > N) s.h = N;
+  s.G = (N - s.h) >> 2;
+  return s;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sm /*[KT/64]*/) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x < KT / 64) t = sm[threadIdx.x];
+  if (threadIdx.x < 64) t = wave_sum(t);
+  __syncthreads();
+  return t;   // valid in thread 0 (all of wave 0)
+}
+
+// Apply f to every element chunk of row [0, N): f4(offset) for aligned quads, f1(offset) for scalars.
+// Work is distributed grid-stride over blockIdx.x; block 0 also takes the head / tail scalars.
+template <typename F4, typename F1>
+__device__ __forceinline__ void row_apply(const RowSplit s, long long N, F4 f4, F1 f1) {
+  for (long long g = (long long)blockIdx.x * KT + threadIdx.x; g < s.G; g += (long long)gridDim.x * KT)
+    f4(s.h + 4 * g);
+  if (blockIdx.x == 0) {
+    for (long long i = threadIdx.x; i < s.h; i += KT) f1(i);
+    for (long long i = s.h + 4 * s.G + threadIdx.x; i < N; i += KT) f1(i);
+  }
+}
+
+#define LD4(ptr, off) (*reinterpret_cast<const float4*>((ptr) + (off)))
+#define ST4(ptr, off, v) (*reinterpret_cast<float4*>((ptr) + (off)) = (v))
+
+// ---- out[p] = <X[p], Y[p]> --------------------------------------------------------------------------
+__global__ __launch_bounds__(KT) void bdot_kernel(const float* X, const float* Y, float* out, long long N) {
+  __shared__ float sm[KT / 64];
+  const int p = blockIdx.y;
+  const float* x = X + (long long)p * N;
+  const float* y = Y + (long long)p * N;
+  const RowSplit s = split_row(x, N);
+  float acc = 0.f;
+  row_apply(s, N,
+            [&](long long o) { const float4 a = LD4(x, o), b = LD4(y, o); acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; },
+            [&](long long o) { acc += x[o] * y[o]; });
+  const float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(out + p, t);
+}
+
+// ---- Y[p] = ca[p] X[p] + cb[p] Y[p] --------------------------------------------------------------------
+__global__ __launch_bounds__(KT) void axpby_kernel(float* Y, const float* X, const float* a, float a_s,
+                                                   const float* b, float b_s, long long N) {
+  const int p = blockIdx.y;
+  const float ca = a_s * (a ? a[p] : 1.f), cb = b_s * (b ? b[p] : 1.f);
+  const float* x = X + (long long)p * N;
+  float* y = Y + (long long)p * N;
+  const RowSplit s = split_row(x, N);
+  const bool useb = cb != 0.f;   // b == 0: pure scaled copy, Y may hold garbage (NaN-safe)
+  row_apply(s, N,
+            [&](long long o) {
+              const float4 xv = LD4(x, o);
+              float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (useb) yv = LD4(y, o);
+              ST4(y, o, make_float4(ca * xv.x + cb * yv.x, ca * xv.y + cb * yv.y, ca * xv.z + cb * yv.z, ca * xv.w + cb * yv.w));
+            },
+            [&](long long o) { y[o] = ca * x[o] + (useb ? cb * y[o] : 0.f); });
+}
+
+// ---- c[p][j] = <Q[p][j], w[p]>, j < k : each block keeps its chunk of w in registers and streams Q ----
+__global__ __launch_bounds__(KT) void multi_dot_kernel(const float* Q, const float* W, float* c, int k, int kmax,
+                                                       long long N) {
+  extern __shared__ float cs[];   // [k]
+  const int p = blockIdx.y;
+  const float* w = W + (long long)p * N;
+  const float* q0 = Q + (long long)p * kmax * N;
+  for (int j = threadIdx.x; j < k; j += KT) cs[j] = 0.f;
+  __syncthreads();
+  const long long beg = (long long)blockIdx.x * CHUNK;
+  const long long end = beg + CHUNK < N ? beg + CHUNK : N;
+  // element ownership inside the chunk: thread t owns beg + t + i*KT (coalesced dwords; row bases of
+  // different j share the row's misalignment, so dword accesses keep this kernel simple and exact)
+  float wr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long o = beg + threadIdx.x + (long long)i * KT;
+    wr[i] = o < end ? w[o] : 0.f;
+  }
+  for (int j = 0; j < k; ++j) {
+    const float* q = q0 + (long long)j * N;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long o = beg + threadIdx.x + (long long)i * KT;
+      if (o < end) acc += q[o] * wr[i];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&cs[j], acc);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < k; j += KT) atomicAdd(c + (long long)p * kmax + j, cs[j]);
+}
+
+// ---- w[p] -= sum_j c[p][j] Q[p][j] ; nrm2[p] = ||w[p]||^2 ------------------------------------------------
+__global__ __launch_bounds__(KT) void multi_axpy_norm_kernel(const float* Q, const float* c, float* W, float* nrm2,
+                                                             int k, int kmax, long long N) {
+  extern __shared__ float cs[];   // [k]
+  __shared__ float sm[KT / 64];
+  const int p = blockIdx.y;
+  float* w = W + (long long)p * N;
+  const float* q0 = Q + (long long)p * kmax * N;
+  for (int j = threadIdx.x; j < k; j += KT) cs[j] = c[(long long)p * kmax + j];
+  __syncthreads();
+  const long long beg = (long long)blockIdx.x * CHUNK;
+  const long long end = beg + CHUNK < N ? beg + CHUNK : N;
+  float wr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long o = beg + threadIdx.x + (long long)i * KT;
+    wr[i] = o < end ? w[o] : 0.f;
+  }
+  for (int j = 0; j < k; ++j) {
+    const float* q = q0 + (long long)j * N;
+    const float cj = cs[j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long o = beg + threadIdx.x + (long long)i * KT;
+      if (o < end) wr[i] -= cj * q[o];
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long o = beg + threadIdx.x + (long long)i * KT;
+    if (o < end) { w[o] = wr[i]; acc += wr[i] * wr[i]; }
+  }
+  const float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(nrm2 + p, t);
+}
+
+// ---- Q[p][j] = w[p] / sqrt(nrm2[p]) ----------------------------------------------------------------------
+__global__ __launch_bounds__(KT) void scale_store_kernel(const float* W, const float* nrm2, float* Q, int j, int kmax,
+                                                         long long N) {
+  const int p = blockIdx.y;
+  const float inv = rsqrtf(nrm2[p]);
+  const float* w = W + (long long)p * N;
+  float* q = Q + ((long long)p * kmax + j) * N;
+  for (long long o = (long long)blockIdx.x * KT + threadIdx.x; o < N; o += (long long)gridDim.x * KT) q[o] = w[o] * inv;
+}
+
+// ---- fused CG update: a = rr_old/pAp ; x += a p ; r -= a Ap ; rr_new = <r, r> ------------------------------
+__global__ __launch_bounds__(KT) void cg_update_kernel(float* X, float* R, const float* Pd, const float* AP,
+                                                       const float* rr_old, const float* pAp, const int* active,
+                                                       float* rr_new, long long N) {
+  __shared__ float sm[KT / 64];
+  const int p = blockIdx.y;
+  if (active && !active[p]) return;
+  const float a = rr_old[p] / pAp[p];
+  float* x = X + (long long)p * N;
+  float* r = R + (long long)p * N;
+  const float* pd = Pd + (long long)p * N;
+  const float* ap = AP + (long long)p * N;
+  const RowSplit s = split_row(x, N);
+  float acc = 0.f;
+  row_apply(s, N,
+            [&](long long o) {
+              const float4 pv = LD4(pd, o), av = LD4(ap, o);
+              float4 xv = LD4(x, o), rv = LD4(r, o);
+              xv.x += a * pv.x; xv.y += a * pv.y; xv.z += a * pv.z; xv.w += a * pv.w;
+              rv.x -= a * av.x; rv.y -= a * av.y; rv.z -= a * av.z; rv.w -= a * av.w;
+              ST4(x, o, xv); ST4(r, o, rv);
+              acc += rv.x * rv.x + rv.y * rv.y + rv.z * rv.z + rv.w * rv.w;
+            },
+            [&](long long o) {
+              x[o] += a * pd[o];
+              const float rv = r[o] - a * ap[o];
+              r[o] = rv;
+              acc += rv * rv;
+            });
+  const float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(rr_new + p, t);
+}
+
+// ---- p = r + (rr_new/rr_old) p ------------------------------------------------------------------------------
+__global__ __launch_bounds__(KT) void cg_direction_kernel(float* Pd, const float* R, const float* rr_new,
+                                                          const float* rr_old, const int* active, long long N) {
+  const int p = blockIdx.y;
+  if (active && !active[p]) return;
+  const float b = rr_new[p] / rr_old[p];
+  float* pd = Pd + (long long)p * N;
+  const float* r = R + (long long)p * N;
+  const RowSplit s = split_row(pd, N);
+  row_apply(s, N,
+            [&](long long o) {
+              const float4 rv = LD4(r, o); float4 pv = LD4(pd, o);
+              pv.x = rv.x + b * pv.x; pv.y = rv.y + b * pv.y; pv.z = rv.z + b * pv.z; pv.w = rv.w + b * pv.w;
+              ST4(pd, o, pv);
+            },
+            [&](long long o) { pd[o] = r[o] + b * pd[o]; });
+}
+
+// ---- counter-based RNG: Philox4x32-10, counter = flat element index / 4, key = seed ---------------------------
+__device__ __forceinline__ void philox4x32(unsigned long long ctr, unsigned long long key, unsigned int (&out)[4]) {
+  unsigned int c0 = (unsigned int)ctr, c1 = (unsigned int)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
+  unsigned int k0 = (unsigned int)key, k1 = (unsigned int)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long m0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long m1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned int n0 = (unsigned int)(m1 >> 32) ^ c1 ^ k0;
+    const unsigned int n1 = (unsigned int)m1;
+    const unsigned int n2 = (unsigned int)(m0 >> 32) ^ c3 ^ k1;
+    const unsigned int n3 = (unsigned int)m0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <bool NORMAL>
+__global__ __launch_bounds__(KT) void fill_kernel(float* X, long long total, unsigned long long seed) {
+  const long long nq = (total + 3) >> 2;
+  for (long long q = (long long)blockIdx.x * KT + threadIdx.x; q < nq; q += (long long)gridDim.x * KT) {
+    unsigned int u[4];
+    philox4x32((unsigned long long)q, seed, u);
+    float v[4];
+    if (NORMAL) {
+      // Box-Muller on two uniform pairs
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(u[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(u[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        v[2 * h] = rad * cs; v[2 * h + 1] = rad * sn;
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) v[h] = (u[h] & 0x80000000u) ? 1.f : -1.f;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const long long o = 4 * q + h;
+      if (o < total) X[o] = v[h];
+    }
+  }
+}
+
+static inline unsigned nblk_for(long long N, long long per_block, unsigned cap) {
+  long long b = (N + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+static bool same_alignment(const void* a, const void* b) {
+  return (((unsigned long long)a ^ (unsigned long long)b) & 15ull) == 0;
+}
+
+}  // namespace lip
+
+using namespace lip;
+
+#define LIP_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) { set_error("%s: %s", #expr, hipGetErrorString(_e)); return LIP_ERR_HIP; } \
+  } while (0)
+
+extern "C" {
+
+int lip_bdot(const float* X, const float* Y, float* out, int32_t P, int64_t N, void* stream) {
+  if (!X || !Y || !out || P <= 0 || N <= 0) { set_error("lip_bdot: bad argument"); return LIP_ERR_ARG; }
+  if (!same_alignment(X, Y) ) { set_error("lip_bdot: X and Y must share 16-byte alignment"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  LIP_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * P, st));
+  hipLaunchKernelGGL(bdot_kernel, dim3(nblk_for(N, CHUNK * 4, 256), P), dim3(KT), 0, st, X, Y, out, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_axpby(float* Y, const float* X, const float* a, float a_s, const float* b, float b_s, int32_t P, int64_t N,
+              void* stream) {
+  if (!X || !Y || P <= 0 || N <= 0) { set_error("lip_axpby: bad argument"); return LIP_ERR_ARG; }
+  if (!same_alignment(X, Y)) { set_error("lip_axpby: X and Y must share 16-byte alignment"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(axpby_kernel, dim3(nblk_for(N, CHUNK, 2048), P), dim3(KT), 0, st, Y, X, a, a_s, b, b_s, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_multi_dot(const float* Q, const float* w, float* c, int32_t P, int32_t k, int32_t kmax, int64_t N, void* stream) {
+  if (!Q || !w || !c || P <= 0 || k <= 0 || k > kmax || N <= 0 || k > 8192) { set_error("lip_multi_dot: bad argument"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  LIP_CHECK_HIP(hipMemset2DAsync(c, sizeof(float) * kmax, 0, sizeof(float) * k, P, st));
+  const unsigned nb = (unsigned)((N + CHUNK - 1) / CHUNK);
+  hipLaunchKernelGGL(multi_dot_kernel, dim3(nb, P), dim3(KT), sizeof(float) * k, st, Q, w, c, k, kmax, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_multi_axpy_norm(const float* Q, const float* c, float* w, float* nrm2, int32_t P, int32_t k, int32_t kmax,
+                        int64_t N, void* stream) {
+  if (!Q || !w || !c || !nrm2 || P <= 0 || k <= 0 || k > kmax || N <= 0 || k > 8192) { set_error("lip_multi_axpy_norm: bad argument"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  LIP_CHECK_HIP(hipMemsetAsync(nrm2, 0, sizeof(float) * P, st));
+  const unsigned nb = (unsigned)((N + CHUNK - 1) / CHUNK);
+  hipLaunchKernelGGL(multi_axpy_norm_kernel, dim3(nb, P), dim3(KT), sizeof(float) * k, st, Q, c, w, nrm2, k, kmax, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_scale_store(const float* w, const float* nrm2, float* Q, int32_t j, int32_t P, int32_t kmax, int64_t N,
+                    void* stream) {
+  if (!Q || !w || !nrm2 || P <= 0 || j < 0 || j >= kmax || N <= 0) { set_error("lip_scale_store: bad argument"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(scale_store_kernel, dim3(nblk_for(N, CHUNK, 2048), P), dim3(KT), 0, st, w, nrm2, Q, j, kmax, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_cg_update(float* x, float* r, const float* p, const float* Ap, const float* rr_old, const float* pAp,
+                  const int32_t* active, float* rr_new, int32_t P, int64_t N, void* stream) {
+  if (!x || !r || !p || !Ap || !rr_old || !pAp || !rr_new || P <= 0 || N <= 0) { set_error("lip_cg_update: bad argument"); return LIP_ERR_ARG; }
+  if (!same_alignment(x, r) || !same_alignment(x, p) || !same_alignment(x, Ap)) { set_error("lip_cg_update: blocks must share 16-byte alignment"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  LIP_CHECK_HIP(hipMemsetAsync(rr_new, 0, sizeof(float) * P, st));
+  hipLaunchKernelGGL(cg_update_kernel, dim3(nblk_for(N, CHUNK * 2, 1024), P), dim3(KT), 0, st, x, r, p, Ap, rr_old, pAp,
+                     (const int*)active, rr_new, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_cg_direction(float* p, const float* r, const float* rr_new, const float* rr_old, const int32_t* active, int32_t P,
+                     int64_t N, void* stream) {
+  if (!p || !r || !rr_new || !rr_old || P <= 0 || N <= 0) { set_error("lip_cg_direction: bad argument"); return LIP_ERR_ARG; }
+  if (!same_alignment(p, r)) { set_error("lip_cg_direction: blocks must share 16-byte alignment"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cg_direction_kernel, dim3(nblk_for(N, CHUNK, 2048), P), dim3(KT), 0, st, p, r, rr_new, rr_old,
+                     (const int*)active, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_fill_rademacher(float* X, int32_t P, int64_t N, uint64_t seed, void* stream) {
+  if (!X || P <= 0 || N <= 0) { set_error("lip_fill_rademacher: bad argument"); return LIP_ERR_ARG; }
+  const long long total = (long long)P * N;
+  hipLaunchKernelGGL((fill_kernel<false>), dim3(nblk_for(total, KT * 16, 8192)), dim3(KT), 0, (hipStream_t)stream, X, total,
+                     (unsigned long long)seed);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_fill_normal(float* X, int32_t P, int64_t N, uint64_t seed, void* stream) {
+  if (!X || P <= 0 || N <= 0) { set_error("lip_fill_normal: bad argument"); return LIP_ERR_ARG; }
+  const long long total = (long long)P * N;
+  hipLaunchKernelGGL((fill_kernel<true>), dim3(nblk_for(total, KT * 16, 8192)), dim3(KT), 0, (hipStream_t)stream, X, total,
+                     (unsigned long long)seed);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+// MFMA kernels of the linearised-network engine (gfx950 / CDNA4, wave64).
+//
+//  igemm_kernel : implicit-GEMM convolution / dense layer with up to three K-segments and a
+//                 fused epilogue.  One launch is
+//                   * a tangent-forward layer   dz = conv(da, W) + conv(a, dW_p)   (K1 of SURVEY §2.2,
+//                     reference src/ggn.py:59,139 jax.jvp) with the BN / bias / residual / act'
+//                     tangent fused in the epilogue,
+//                   * a data-gradient layer     g_in = act' * (convT(g, W^T s) [+ convT(g2, ..)] + res)
+//                     (K3, reference src/ggn.py:75-76,142-143 jax.vjp) with the bias / BN parameter
+//                     cotangents reduced from the tile,
+//                   * or a primal layer (P = 1).
+//  wgrad_kernel : per-probe weight cotangent  dW_p = s * sum_{i,pix} im2col(a_i)^T g_{i,p}, written
+//                 straight into the caller's (P, D) output block — the sum over examples happens in
+//                 the MFMA K dimension; no (M, D) per-example intermediate exists
+//                 (the reference materialises it: src/ggn.py:89-91).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain), so the
+// results are exact-f32 GEMMs; dtype "f32".  Operand maps (cdna_hip_programming.md §3):
+//   A: lane l holds A[i = l&31][k = l>>5],  B: lane l holds B[k = l>>5][j = l&31],
+//   C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// LDS images are k-major (As[k][m], Bs[k][n]) so every MFMA operand read is 32 consecutive
+// dwords per half-wave: conflict-free ds_read_b32.
+#include "lip_internal.h"
+
+namespace lip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+template <int WM, int WN, int TM, int TN>
+struct Tile {
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int BM = WM * TM * 32;
+  static constexpr int BN = WN * TN * 32;
+  static constexpr int AE = BM * BK / NT;   // A floats per thread per K-tile
+  static constexpr int AQ = AE / 4;         // A float4 per thread per K-tile
+  static constexpr int BE = BN * BK / NT;   // B floats per thread per K-tile
+};
+
+// One BK-deep MFMA sweep over the LDS tiles.
+template <int WM, int WN, int TM, int TN, int LDA, int LDB>
+__device__ __forceinline__ void mfma_sweep(const float* __restrict__ As, const float* __restrict__ Bs,
+                                           f32x16 (&acc)[TM][TN], int wm, int wn, int lane) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK / 2; ++kk) {
+    const int krow = 2 * kk + lh;
+    float a[TM], b[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[tm] = As[krow * LDA + (wm * TM + tm) * 32 + l31];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[krow * LDB + (wn * TN + tn) * 32 + l31];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// implicit GEMM
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
+  using T = Tile<WM, WN, TM, TN>;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
+  constexpr int LDA = BM + 2, LDB = BN;
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+  __shared__ float redbuf[2 * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int N = prm.N, R = prm.R;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int p = blockIdx.y;
+  const int r0 = tile_m * BM, n0 = tile_n * BN;
+
+  for (int i = tid; i < 2 * BN; i += NT) redbuf[i] = 0.f;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  // rows owned by this thread in the vector A-load path: quad q = tid + j*NT -> (m = q>>2, kq = q&3)
+  int vi[AQ], voh[AQ], vow[AQ];
+#pragma unroll
+  for (int j = 0; j < AQ; ++j) {
+    const int m = (tid + j * NT) >> 2;
+    const int r = r0 + m;
+    if (r < R) {
+      const int i = r / prm.OHW, rem = r - i * prm.OHW;
+      vi[j] = i; voh[j] = rem / prm.OW; vow[j] = rem - voh[j] * prm.OW;
+    } else {
+      vi[j] = -1; voh[j] = 0; vow[j] = 0;
+    }
+  }
+
+  float areg[AE], breg[BE];
+
+  auto gather_coord = [](const SegP& s, int o, int k, int pad, int lim, int& valid) -> int {
+    int t;
+    if (s.mode == 0) {
+      t = o * s.stride + k - pad;
+    } else {
+      t = o + pad - k;
+      if (t < 0 || (t % s.stride) != 0) { valid = 0; return 0; }
+      t /= s.stride;
+    }
+    if (t < 0 || t >= lim) valid = 0;
+    return t;
+  };
+
+  auto load_tile = [&](const SegP& s, int k0) {
+    const float* abase = s.a + (long long)p * s.a_ps;
+    if ((s.C & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < AQ; ++j) {
+        const int kq = (tid + j * NT) & 3;
+        const int kg = k0 + kq * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vi[j] >= 0 && kg < s.Ktot) {
+          const int tap = kg / s.C, c = kg - tap * s.C;
+          const int kh = tap / s.KW, kw = tap - kh * s.KW;
+          int valid = 1;
+          const int ih = gather_coord(s, voh[j], kh, s.pad_h, s.IH, valid);
+          const int iw = gather_coord(s, vow[j], kw, s.pad_w, s.IW, valid);
+          if (valid)
+            v = *reinterpret_cast<const float4*>(abase + (((long long)vi[j] * s.IH + ih) * s.IW + iw) * s.C + c);
+        }
+        areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AE; ++j) {
+        const int e = tid + j * NT;
+        const int m = e >> 4, k = e & 15;
+        const int r = r0 + m, kg = k0 + k;
+        float v = 0.f;
+        if (r < R && kg < s.Ktot) {
+          const int i = r / prm.OHW, rem = r - i * prm.OHW;
+          const int oh = rem / prm.OW, ow = rem - oh * prm.OW;
+          const int tap = kg / s.C, c = kg - tap * s.C;
+          const int kh = tap / s.KW, kw = tap - kh * s.KW;
+          int valid = 1;
+          const int ih = gather_coord(s, oh, kh, s.pad_h, s.IH, valid);
+          const int iw = gather_coord(s, ow, kw, s.pad_w, s.IW, valid);
+          if (valid) v = abase[(((long long)i * s.IH + ih) * s.IW + iw) * s.C + c];
+        }
+        areg[j] = v;
+      }
+    }
+    const float* bbase = s.b + (long long)p * s.b_ps;
+#pragma unroll
+    for (int j = 0; j < BE; ++j) {
+      const int e = tid + j * NT;
+      const int k = e / BN, nn = e - k * BN;
+      const int kg = k0 + k, col = n0 + nn;
+      breg[j] = (kg < s.Ktot && col < N) ? bbase[(long long)kg * N + col] : 0.f;
+    }
+  };
+
+  auto store_tile = [&](const SegP& s) {
+    if ((s.C & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < AQ; ++j) {
+        const int q = tid + j * NT;
+        const int m = q >> 2, kq = q & 3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) As[(4 * kq + t) * LDA + m] = areg[4 * j + t];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AE; ++j) {
+        const int e = tid + j * NT;
+        As[(e & 15) * LDA + (e >> 4)] = areg[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BE; ++j) {
+      const int e = tid + j * NT;
+      const int k = e / BN, nn = e - k * BN;
+      Bs[k * LDB + nn] = breg[j];
+    }
+  };
+
+  int seg = 0, k0 = 0;
+  load_tile(prm.seg[0], 0);
+  while (true) {
+    __syncthreads();
+    store_tile(prm.seg[seg]);
+    __syncthreads();
+    k0 += BK;
+    if (k0 >= prm.seg[seg].Ktot) { ++seg; k0 = 0; }
+    const bool more = seg < prm.nseg;
+    if (more) load_tile(prm.seg[seg], k0);
+    mfma_sweep<WM, WN, TM, TN, LDA, LDB>(As, Bs, acc, wm, wn, lane);
+    if (!more) break;
+  }
+
+  // ---- fused epilogue --------------------------------------------------------------------
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int cl = (wn * TN + tn) * 32 + l31;
+    const int col = n0 + cl;
+    const bool cv = col < N;
+    const float sc = (prm.scale && cv) ? prm.scale[col] : 1.f;
+    const float e0v = (prm.e0 && cv) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
+    const float e1v = (prm.e1 && cv) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = r0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (r < R && cv) {
+          const long long idx = (long long)r * N + col;
+          float v = acc[tm][tn][reg] * sc + e0v;
+          if (prm.e1) v += e1v * prm.xhat[idx];
+          if (prm.res) v += prm.res[(long long)p * prm.res_ps + idx];
+          if (prm.dphi) v *= prm.dphi[idx];
+          prm.out[(long long)p * prm.out_ps + idx] = v;
+          s0 += v;
+          if (prm.red1) s1 += v * prm.xhat2[idx];
+        }
+      }
+    }
+    if (do_red) {
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (lh == 0) {
+        atomicAdd(&redbuf[cl], s0);
+        atomicAdd(&redbuf[BN + cl], s1);
+      }
+    }
+  }
+  if (do_red) {
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      const int col = n0 + c;
+      if (col < N) {
+        if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + col, redbuf[c]);
+        if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + col, redbuf[BN + c]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
+  using T = Tile<WM, WN, TM, TN>;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
+  constexpr int LDA = BM + 4, LDB = BN;
+  constexpr int QPR = BM / 4;              // float4 per LDS row
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int N = prm.N, M = prm.M;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int p = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  int rows_per = (prm.R + prm.ksplit - 1) / prm.ksplit;
+  rows_per = (rows_per + BK - 1) / BK * BK;
+  const int rbeg = blockIdx.z * rows_per;
+  const int rend = min(prm.R, rbeg + rows_per);
+  if (rbeg >= rend) return;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const bool vec = (prm.C & 3) == 0;
+  // this thread's m (fixed across the K loop): vector path m = m0 + 4*(tid % QPR); scalar m0 + tid % BM
+  const int my_m = vec ? (m0 + 4 * (tid % QPR)) : (m0 + (tid % BM));
+  int kh = 0, kw = 0, ci = 0;
+  const bool mvalid = my_m < M;
+  if (mvalid) {
+    const int tap = my_m / prm.C;
+    ci = my_m - tap * prm.C;
+    kh = tap / prm.KW;
+    kw = tap - kh * prm.KW;
+  }
+
+  float areg[AE], breg[BE];
+  const float* gbase = prm.g + (long long)p * prm.g_ps;
+
+  auto load_tile = [&](int rk0) {
+    if (vec) {
+#pragma unroll
+      for (int j = 0; j < AQ; ++j) {
+        const int k = (tid + j * NT) / QPR;
+        const int r = rk0 + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mvalid && r < rend) {
+          const int i = r / prm.OHW, rem = r - i * prm.OHW;
+          const int oh = rem / prm.OW, ow = rem - oh * prm.OW;
+          const int ih = oh * prm.stride + kh - prm.pad_h, iw = ow * prm.stride + kw - prm.pad_w;
+          if (ih >= 0 && ih < prm.IH && iw >= 0 && iw < prm.IW)
+            v = *reinterpret_cast<const float4*>(prm.a + (((long long)i * prm.IH + ih) * prm.IW + iw) * prm.C + ci);
+        }
+        areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AE; ++j) {
+        const int k = (tid + j * NT) / BM;
+        const int r = rk0 + k;
+        float v = 0.f;
+        if (mvalid && r < rend) {
+          const int i = r / prm.OHW, rem = r - i * prm.OHW;
+          const int oh = rem / prm.OW, ow = rem - oh * prm.OW;
+          const int ih = oh * prm.stride + kh - prm.pad_h, iw = ow * prm.stride + kw - prm.pad_w;
+          if (ih >= 0 && ih < prm.IH && iw >= 0 && iw < prm.IW)
+            v = prm.a[(((long long)i * prm.IH + ih) * prm.IW + iw) * prm.C + ci];
+        }
+        areg[j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BE; ++j) {
+      const int e = tid + j * NT;
+      const int k = e / BN, nn = e - k * BN;
+      const int r = rk0 + k, col = n0 + nn;
+      breg[j] = (r < rend && col < N) ? gbase[(long long)r * N + col] : 0.f;
+    }
+  };
+
+  auto store_tile = [&]() {
+    if (vec) {
+#pragma unroll
+      for (int j = 0; j < AQ; ++j) {
+        const int q = tid + j * NT;
+        const int k = q / QPR, mq = q - k * QPR;
+        *reinterpret_cast<float4*>(&As[k * LDA + 4 * mq]) =
+            make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AE; ++j) {
+        const int e = tid + j * NT;
+        const int k = e / BM, mm = e - k * BM;
+        As[k * LDA + mm] = areg[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BE; ++j) {
+      const int e = tid + j * NT;
+      const int k = e / BN, nn = e - k * BN;
+      Bs[k * LDB + nn] = breg[j];
+    }
+  };
+
+  int rk = rbeg;
+  load_tile(rk);
+  while (true) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    rk += BK;
+    const bool more = rk < rend;
+    if (more) load_tile(rk);
+    mfma_sweep<WM, WN, TM, TN, LDA, LDB>(As, Bs, acc, wm, wn, lane);
+    if (!more) break;
+  }
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* ybase = prm.y + (long long)p * prm.y_ps;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + (wn * TN + tn) * 32 + l31;
+    if (col >= N) continue;
+    const float sc = prm.scale ? prm.scale[col] : 1.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (m < M) {
+          float* dst = ybase + (long long)m * N + col;
+          const float v = acc[tm][tn][reg] * sc;
+          if (prm.ksplit > 1) atomicAdd(dst, v);
+          else *dst += v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers: pick the tile shape from the problem shape
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
+  using T = Tile<WM, WN, TM, TN>;
+  const long long tiles = (long long)((p.R + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
+  dim3 grid((unsigned)tiles, (unsigned)P, 1);
+  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
+  const bool small_m = p.R <= 64;
+  if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);
+  if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st);
+  return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st);
+}
+
+template <int WM, int WN, int TM, int TN>
+static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
+  using T = Tile<WM, WN, TM, TN>;
+  const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
+  dim3 grid((unsigned)tiles, (unsigned)P, (unsigned)p.ksplit);
+  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
+  const bool small_m = p.M <= 64;
+  if (p.N > 64) return small_m ? run_wgrad<2, 2, 1, 2>(p, P, st) : run_wgrad<2, 2, 2, 2>(p, P, st);
+  if (p.N > 32) return small_m ? run_wgrad<2, 2, 1, 1>(p, P, st) : run_wgrad<4, 1, 1, 2>(p, P, st);
+  return small_m ? run_wgrad<2, 1, 1, 1>(p, P, st) : run_wgrad<4, 1, 1, 1>(p, P, st);
+}
+
+}  // namespace lip

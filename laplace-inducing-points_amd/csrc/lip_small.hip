@@ -1,0 +1,228 @@
+// Non-GEMM kernels of the linearised-network engine: all HBM-bound, coalesced along the channel
+// (innermost NHWC) dimension, wavefront reductions where a sum is needed.
+#include "lip_internal.h"
+
+namespace lip {
+
+// ---- per-channel column sums: red0[p][c] += sum_r g[p][r][c] ; red1[p][c] += sum_r g*xhat --------
+// (bias / BN-parameter cotangents that could not be fused into an igemm epilogue)
+constexpr int RED_ROWS = 128;
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceP prm) {
+  extern __shared__ float sm[];           // [2*N]
+  const int N = prm.N, p = blockIdx.y;
+  float* s0 = sm; float* s1 = sm + N;
+  for (int i = threadIdx.x; i < 2 * N; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int rbeg = blockIdx.x * RED_ROWS;
+  const int rows = min(RED_ROWS, prm.R - rbeg);
+  const float* g = prm.g + (long long)p * prm.g_ps + (long long)rbeg * N;
+  const float* xh = prm.xhat ? prm.xhat + (long long)rbeg * N : nullptr;
+  const long long cnt = (long long)rows * N;
+  if (N <= 256 && (256 % N) == 0) {
+    // fixed channel per thread: accumulate privately, one LDS atomic per thread
+    const int c = threadIdx.x % N;
+    float a0 = 0.f, a1 = 0.f;
+    for (long long idx = threadIdx.x; idx < cnt; idx += 256) {
+      const float v = g[idx];
+      a0 += v;
+      if (xh) a1 += v * xh[idx];
+    }
+    atomicAdd(&s0[c], a0);
+    if (xh) atomicAdd(&s1[c], a1);
+  } else {
+    for (long long idx = threadIdx.x; idx < cnt; idx += 256) {
+      const int c = (int)(idx % N);
+      const float v = g[idx];
+      atomicAdd(&s0[c], v);
+      if (xh) atomicAdd(&s1[c], v * xh[idx]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < N; c += 256) {
+    if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + c, s0[c]);
+    if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + c, s1[c]);
+  }
+}
+
+hipError_t launch_reduce(const ReduceP& p, int P, hipStream_t st) {
+  dim3 grid((p.R + RED_ROWS - 1) / RED_ROWS, P, 1);
+  hipLaunchKernelGGL(reduce_kernel, grid, dim3(256), 2 * p.N * sizeof(float), st, p);
+  return hipGetLastError();
+}
+
+// ---- mean pool over pixels: out[p][i][c] = inv * sum_pix in[p][i][pix][c]  (jnp.mean(x,(1,2))) ------
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolP prm) {
+  extern __shared__ float sm[];           // [C]
+  const int C = prm.C, i = blockIdx.x, p = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += 256) sm[c] = 0.f;
+  __syncthreads();
+  const float* in = prm.in + (long long)p * prm.in_ps + (long long)i * prm.HW * C;
+  const long long cnt = (long long)prm.HW * C;
+  if (C <= 256 && (256 % C) == 0) {
+    const int c = threadIdx.x % C;
+    float a = 0.f;
+    for (long long idx = threadIdx.x; idx < cnt; idx += 256) a += in[idx];
+    atomicAdd(&sm[c], a);
+  } else {
+    for (long long idx = threadIdx.x; idx < cnt; idx += 256) atomicAdd(&sm[idx % C], in[idx]);
+  }
+  __syncthreads();
+  float* out = prm.out + (long long)p * prm.out_ps + (long long)i * C;
+  for (int c = threadIdx.x; c < C; c += 256) out[c] = sm[c] * prm.inv;
+}
+
+hipError_t launch_pool_fwd(const PoolP& p, int P, hipStream_t st) {
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(p.n, P, 1), dim3(256), p.C * sizeof(float), st, p);
+  return hipGetLastError();
+}
+
+// ---- pool backward: out[p][i][pix][c] = dphi[i][pix][c] * inv * in[p][i][c], plus reductions ------------
+constexpr int PB_PIX = 16;
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolP prm) {
+  extern __shared__ float sm[];           // [2*C]
+  const int C = prm.C, i = blockIdx.y, p = blockIdx.z;
+  float* s0 = sm; float* s1 = sm + C;
+  const bool red = prm.red0 || prm.red1;
+  if (red) {
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    __syncthreads();
+  }
+  const int pbeg = blockIdx.x * PB_PIX;
+  const int npix = min(PB_PIX, prm.HW - pbeg);
+  const float* in = prm.in + (long long)p * prm.in_ps + (long long)i * C;
+  const long long base = ((long long)i * prm.HW + pbeg) * C;
+  float* out = prm.out + (long long)p * prm.out_ps + base;
+  const long long cnt = (long long)npix * C;
+  for (long long idx = threadIdx.x; idx < cnt; idx += 256) {
+    const int c = (int)(idx % C);
+    float v = in[c] * prm.inv;
+    if (prm.dphi) v *= prm.dphi[base + idx];
+    out[idx] = v;
+    if (red) {
+      atomicAdd(&s0[c], v);
+      if (prm.red1) atomicAdd(&s1[c], v * prm.xhat[base + idx]);
+    }
+  }
+  if (red) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + c, s0[c]);
+      if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + c, s1[c]);
+    }
+  }
+}
+
+hipError_t launch_pool_bwd(const PoolP& p, int P, hipStream_t st) {
+  dim3 grid((p.HW + PB_PIX - 1) / PB_PIX, p.n, P);
+  hipLaunchKernelGGL(pool_bwd_kernel, grid, dim3(256), 2 * p.C * sizeof(float), st, p);
+  return hipGetLastError();
+}
+
+// ---- primal post-processing: z -> (xhat, a = act(y), dphi = act'(y)),  y = BN(z + bias) + res --------
+__device__ __forceinline__ void act_eval(int act, float y, float& a, float& d) {
+  if (act == 1) { a = y > 0.f ? y : 0.f; d = y > 0.f ? 1.f : 0.f; }
+  else if (act == 2) { const float t = tanhf(y); a = t; d = 1.f - t * t; }
+  else if (act == 3) {  // tanh-form GELU (flax.linen.gelu default approximate=True; src/toymodels.py:11)
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (y + k1 * y * y * y);
+    const float t = tanhf(u);
+    a = 0.5f * y * (1.f + t);
+    d = 0.5f * (1.f + t) + 0.5f * y * (1.f - t * t) * k0 * (1.f + 3.f * k1 * y * y);
+  } else { a = y; d = 1.f; }
+}
+
+__global__ __launch_bounds__(256) void primal_post_kernel(const PrimalPostP prm) {
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < prm.count;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % prm.N);
+    float y = prm.z[idx];
+    if (prm.bias) y += prm.bias[c];
+    if (prm.gamma) {
+      const float xh = (y - prm.mean[c]) * prm.rstd[c];
+      if (prm.xhat) prm.xhat[idx] = xh;
+      y = xh * prm.gamma[c] + prm.beta[c];
+    }
+    if (prm.res) y += prm.res[idx];
+    float a, d;
+    act_eval(prm.act, y, a, d);
+    prm.a[idx] = a;
+    if (prm.dphi) prm.dphi[idx] = d;
+  }
+}
+
+hipError_t launch_primal_post(const PrimalPostP& p, hipStream_t st) {
+  const long long blocks = (p.count + 255) / 256;
+  hipLaunchKernelGGL(primal_post_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// ---- softmax of the primal logits (one wave per example): p and sqrt(p)  (src/ggn.py:23-24,127) ------
+__global__ __launch_bounds__(64) void softmax_kernel(const float* logits, float* prob, float* sqrtp, int n, int K) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const float* f = logits + (long long)i * K;
+  float mx = -3.0e38f;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, f[k]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += expf(f[k] - mx);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int k = lane; k < K; k += 64) {
+    const float pk = expf(f[k] - mx) * inv;
+    prob[(long long)i * K + k] = pk;
+    sqrtp[(long long)i * K + k] = sqrtf(pk);
+  }
+}
+
+hipError_t launch_softmax(const float* logits, float* prob, float* sqrtp, int n, int K, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_kernel, dim3(n), dim3(64), 0, st, logits, prob, sqrtp, n, K);
+  return hipGetLastError();
+}
+
+// ---- output-space head: Hessian / square-root-factor action per (probe, example) ----------------------
+//   GGN : g = c (p.u - p (p^T u))                 src/ggn.py:125-131
+//   LT  : U = c (s.u - (p^T u) s)                 src/ggn.py:29-39
+//   L   : g = c (s.u - (s^T u) p)                 src/ggn.py:16-27
+//   regressor: every mode multiplies by c (c carries exp(-logvar) or its square root, src/ggn.py:17-19,112-113)
+__global__ __launch_bounds__(64) void head_kernel(const HeadP prm) {
+  const int i = blockIdx.x, p = blockIdx.y, lane = threadIdx.x, K = prm.K;
+  const float* u = prm.in + (long long)p * prm.in_ps + (long long)i * K;
+  float* o = prm.out + (long long)p * prm.out_ps + (long long)i * K;
+  if (!prm.classifier || prm.mode == LIP_HEAD_OUT || prm.mode == LIP_HEAD_IN) {
+    for (int k = lane; k < K; k += 64) o[k] = prm.c * u[k];
+    return;
+  }
+  const float* pp = prm.p + (long long)i * K;
+  const float* ss = prm.s + (long long)i * K;
+  float dot = 0.f;
+  if (prm.mode == LIP_HEAD_L) { for (int k = lane; k < K; k += 64) dot += ss[k] * u[k]; }
+  else                        { for (int k = lane; k < K; k += 64) dot += pp[k] * u[k]; }
+  dot = wave_sum(dot);
+  for (int k = lane; k < K; k += 64) {
+    float v;
+    if (prm.mode == LIP_HEAD_GGN)      v = pp[k] * (u[k] - dot);
+    else if (prm.mode == LIP_HEAD_LT)  v = ss[k] * (u[k] - dot);
+    else                               v = ss[k] * u[k] - dot * pp[k];
+    o[k] = prm.c * v;
+  }
+}
+
+hipError_t launch_head(const HeadP& p, int P, hipStream_t st) {
+  hipLaunchKernelGGL(head_kernel, dim3(p.n, P, 1), dim3(64), 0, st, p);
+  return hipGetLastError();
+}
+
+// ---- y = a * x (initialises the output block with the prior-precision term alpha*V, src/lla.py:21-22) --
+__global__ __launch_bounds__(256) void scale_copy_kernel(float* y, const float* x, float a, long long count) {
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256)
+    y[idx] = a * x[idx];
+}
+
+hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st) {
+  const long long blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, y, x, a, count);
+  return hipGetLastError();
+}
+
+}  // namespace lip

@@ -1,0 +1,240 @@
+"""CPU (float64) emulator of the op-tape semantics of ``include/lip.h`` — TEST INFRASTRUCTURE.
+
+It executes the *lowered* tapes (the exact ctypes structs the HIP engine receives) with plain
+torch indexing, following the op definitions literally (gather formulas of ``lip_seg_t``).  Used
+(a) on the CPU to validate the NetSpec -> tape compiler against the oracle and (b) on the GPU box
+to localise a kernel bug op by op (``lip_debug_run_ops``).
+"""
+import torch
+
+from lip_amd import _native as nv
+
+F64 = torch.float64
+
+
+class TapeMachine:
+    def __init__(self, cn, theta, consts, Z, chunk):
+        self.cn, self.chunk = cn, chunk
+        self.theta = theta.to(F64).reshape(-1)
+        self.consts = consts.to(F64).reshape(-1)
+        self.prim = torch.zeros(cn.prim_floats, dtype=F64)
+        nin = Z.numel()
+        self.prim[cn.input_off:cn.input_off + nin] = Z.to(F64).reshape(-1)
+        self.work = torch.zeros(cn.work_pp * chunk, dtype=F64)
+        self.V = self.Y = self.H = None
+
+    # ------------------------------------------------------------------ operand access
+    def _buf(self, space):
+        return {nv.SP_THETA: self.theta, nv.SP_CONST: self.consts, nv.SP_PRIM: self.prim, nv.SP_WORK: self.work,
+                nv.SP_VIN: self.V, nv.SP_YOUT: self.Y, nv.SP_HEAD: self.H}[space]
+
+    def view(self, ref, P, count):
+        """(P, count) strided view of an operand (P = 1 rows for shared operands)."""
+        if ref.space == nv.SP_NONE:
+            return None
+        buf = self._buf(ref.space)
+        off = ref.off * (self.chunk if ref.space == nv.SP_WORK else 1)
+        ps = ref.pstride
+        return torch.as_strided(buf, (P, count), (ps, 1), off)
+
+    # ------------------------------------------------------------------ ops
+    def _gather(self, seg, P, n, OH, OW):
+        """im2col per lip_seg_t: returns A (Pa, n*OH*OW, KH*KW*C) with Pa in {1, P}."""
+        Pa = P if seg.a.pstride != 0 else 1
+        a = self.view(seg.a, Pa, n * seg.IH * seg.IW * seg.C).reshape(Pa, n, seg.IH, seg.IW, seg.C)
+        cols = torch.zeros(Pa, n, OH, OW, seg.KH, seg.KW, seg.C, dtype=F64)
+        for kh in range(seg.KH):
+            for kw in range(seg.KW):
+                for oh in range(OH):
+                    if seg.mode == 0:
+                        ih = oh * seg.stride + kh - seg.pad_h
+                    else:
+                        t = oh + seg.pad_h - kh
+                        if t < 0 or t % seg.stride:
+                            continue
+                        ih = t // seg.stride
+                    if ih < 0 or ih >= seg.IH:
+                        continue
+                    for ow in range(OW):
+                        if seg.mode == 0:
+                            iw = ow * seg.stride + kw - seg.pad_w
+                        else:
+                            t = ow + seg.pad_w - kw
+                            if t < 0 or t % seg.stride:
+                                continue
+                            iw = t // seg.stride
+                        if iw < 0 or iw >= seg.IW:
+                            continue
+                        cols[:, :, oh, ow, kh, kw, :] = a[:, :, ih, iw, :]
+        return cols.reshape(Pa, n * OH * OW, seg.KH * seg.KW * seg.C)
+
+    def igemm(self, op, P):
+        n, OH, OW, N = op.n_img, op.OH, op.OW, op.N
+        R = n * OH * OW
+        acc = torch.zeros(P, R, N, dtype=F64)
+        for s in range(op.nseg):
+            seg = op.seg[s]
+            A = self._gather(seg, P, n, OH, OW)
+            Kt = seg.KH * seg.KW * seg.C
+            Pb = P if seg.b.pstride != 0 else 1
+            B = self.view(seg.b, Pb, Kt * N).reshape(Pb, Kt, N)
+            acc = acc + torch.matmul(A, B)
+        v = acc
+        if op.scale.space != nv.SP_NONE:
+            v = v * self.view(op.scale, 1, N).reshape(1, 1, N)
+        if op.e0.space != nv.SP_NONE:
+            Pe = P if op.e0.pstride != 0 else 1
+            v = v + self.view(op.e0, Pe, N).reshape(Pe, 1, N)
+        if op.e1.space != nv.SP_NONE:
+            Pe = P if op.e1.pstride != 0 else 1
+            v = v + self.view(op.e1, Pe, N).reshape(Pe, 1, N) * self.view(op.xhat, 1, R * N).reshape(1, R, N)
+        if op.res.space != nv.SP_NONE:
+            Pr = P if op.res.pstride != 0 else 1
+            v = v + self.view(op.res, Pr, R * N).reshape(Pr, R, N)
+        if op.dphi.space != nv.SP_NONE:
+            v = v * self.view(op.dphi, 1, R * N).reshape(1, R, N)
+        self.view(op.out, P, R * N).copy_(v.reshape(P, R * N))
+        self._reds(op, v, P, R, N)
+
+    def _reds(self, op, v, P, R, N):
+        if op.red0.space != nv.SP_NONE:
+            self.view(op.red0, P, N).add_(v.sum(1))
+        if op.red1.space != nv.SP_NONE:
+            xh = self.view(op.xhat2, 1, R * N).reshape(1, R, N)
+            self.view(op.red1, P, N).add_((v * xh).sum(1))
+
+    def wgrad(self, op, P):
+        seg = op.seg[0]
+        n, OH, OW, N = op.n_img, op.OH, op.OW, op.N
+        R = n * OH * OW
+        A = self._gather(seg, 1, n, OH, OW)[0]                      # (R, M)
+        g = self.view(seg.b, P, R * N).reshape(P, R, N)
+        dW = torch.matmul(A.T.unsqueeze(0), g)                      # (P, M, N)
+        if op.scale.space != nv.SP_NONE:
+            dW = dW * self.view(op.scale, 1, N).reshape(1, 1, N)
+        M = seg.KH * seg.KW * seg.C
+        self.view(op.out, P, M * N).add_(dW.reshape(P, M * N))
+
+    def reduce(self, op, P):
+        R, N = op.n_img * op.OH * op.OW, op.N
+        g = self.view(op.seg[0].a, P, R * N).reshape(P, R, N)
+        self._reds(op, g, P, R, N)
+
+    def pool_fwd(self, op, P):
+        n, HW, Cc = op.n_img, op.OH * op.OW, op.N
+        Pa = P if op.seg[0].a.pstride != 0 else 1
+        x = self.view(op.seg[0].a, Pa, n * HW * Cc).reshape(Pa, n, HW, Cc)
+        self.view(op.out, Pa, n * Cc).copy_((x.sum(2) * op.fscale).reshape(Pa, n * Cc))
+
+    def pool_bwd(self, op, P):
+        n, HW, Cc = op.n_img, op.OH * op.OW, op.N
+        g = self.view(op.seg[0].a, P, n * Cc).reshape(P, n, 1, Cc)
+        v = (g * op.fscale).expand(P, n, HW, Cc).reshape(P, n * HW, Cc)
+        if op.dphi.space != nv.SP_NONE:
+            v = v * self.view(op.dphi, 1, n * HW * Cc).reshape(1, n * HW, Cc)
+        self.view(op.out, P, n * HW * Cc).copy_(v.reshape(P, -1))
+        self._reds(op, v, P, n * HW, Cc)
+
+    def primal_post(self, op):
+        R, N = op.n_img * op.OH * op.OW, op.N
+        y = self.view(op.seg[0].a, 1, R * N).reshape(R, N).clone()
+        if op.e0.space != nv.SP_NONE:
+            y = y + self.view(op.e0, 1, N)
+        if op.e1.space != nv.SP_NONE:
+            xh = (y - self.view(op.aux0, 1, N)) * self.view(op.aux1, 1, N)
+            self.view(op.out3, 1, R * N).copy_(xh.reshape(1, -1))
+            y = xh * self.view(op.e1, 1, N) + self.view(op.scale, 1, N)
+        if op.res.space != nv.SP_NONE:
+            y = y + self.view(op.res, 1, R * N).reshape(R, N)
+        y = y.clone().requires_grad_(True)
+        from lip_amd.netspec import act_fn
+        name = {0: "none", 1: "relu", 2: "tanh", 3: "gelu"}[op.act]
+        a = act_fn(name, y)
+        d, = torch.autograd.grad(a.sum(), y)
+        self.view(op.out, 1, R * N).copy_(a.detach().reshape(1, -1))
+        if op.out2.space != nv.SP_NONE:
+            self.view(op.out2, 1, R * N).copy_(d.reshape(1, -1))
+
+    def softmax(self, op):
+        n, K = op.n_img, op.N
+        f = self.view(op.seg[0].a, 1, n * K).reshape(n, K)
+        p = torch.softmax(f, -1)
+        self.view(op.out, 1, n * K).copy_(p.reshape(1, -1))
+        self.view(op.out2, 1, n * K).copy_(p.sqrt().reshape(1, -1))
+
+    def head(self, op, P, mode, c):
+        n, K = op.n_img, op.N
+        if mode == nv.HEAD_GGN:
+            rin, rout = op.seg[0].a, op.out
+        elif mode in (nv.HEAD_LT, nv.HEAD_OUT):
+            rin, rout = op.seg[0].a, op.out2
+        else:
+            rin, rout = op.out2, op.out
+        u = self.view(rin, P, n * K).reshape(P, n, K)
+        if (not op.classifier) or mode in (nv.HEAD_OUT, nv.HEAD_IN):
+            v = c * u
+        else:
+            p = self.view(op.aux0, 1, n * K).reshape(1, n, K)
+            s = self.view(op.aux1, 1, n * K).reshape(1, n, K)
+            if mode == nv.HEAD_GGN:
+                v = c * p * (u - (p * u).sum(-1, keepdim=True))
+            elif mode == nv.HEAD_LT:
+                v = c * s * (u - (p * u).sum(-1, keepdim=True))
+            else:
+                v = c * (s * u - (s * u).sum(-1, keepdim=True) * p)
+        self.view(rout, P, n * K).copy_(v.reshape(P, n * K))
+
+    def run_op(self, op, P, mode=0, c=1.0):
+        k = op.kind
+        if k == nv.OP_IGEMM:
+            self.igemm(op, P)
+        elif k == nv.OP_WGRAD:
+            self.wgrad(op, P)
+        elif k == nv.OP_REDUCE:
+            self.reduce(op, P)
+        elif k == nv.OP_POOL_FWD:
+            self.pool_fwd(op, P)
+        elif k == nv.OP_POOL_BWD:
+            self.pool_bwd(op, P)
+        elif k == nv.OP_PRIMAL_POST:
+            self.primal_post(op)
+        elif k == nv.OP_SOFTMAX:
+            self.softmax(op)
+        elif k == nv.OP_HEAD:
+            self.head(op, P, mode, c)
+        else:
+            raise ValueError(k)
+
+    # ------------------------------------------------------------------ entry points (mirror lip.h)
+    def primal(self):
+        for op in self.cn.tapes[0]:
+            self.run_op(op, 1)
+
+    def ggn_vp(self, V, scale, alpha):
+        P = V.shape[0]
+        assert P <= self.chunk
+        self.V = V.to(F64).contiguous().reshape(-1)
+        Y = alpha * V.to(F64)
+        self.Y = Y.contiguous().reshape(-1)
+        for op in self.cn.tapes[1]:
+            self.run_op(op, P, nv.HEAD_GGN, scale)
+        for op in self.cn.tapes[2]:
+            if op.kind != nv.OP_HEAD:
+                self.run_op(op, P)
+        return self.Y.reshape(P, -1)
+
+    def jvp(self, V, mode, c):
+        P = V.shape[0]
+        self.V = V.to(F64).contiguous().reshape(-1)
+        self.H = torch.zeros(P * self.cn.n * self.cn.K, dtype=F64)
+        for op in self.cn.tapes[1]:
+            self.run_op(op, P, mode, c)
+        return self.H.reshape(P, self.cn.n, self.cn.K)
+
+    def vjp(self, U, mode, c):
+        P = U.shape[0]
+        self.H = U.to(F64).contiguous().reshape(-1)
+        self.Y = torch.zeros(P * self.cn.D, dtype=F64)
+        for op in self.cn.tapes[2]:
+            self.run_op(op, P, mode, c)
+        return self.Y.reshape(P, -1)
