@@ -277,9 +277,10 @@ int lip_engine_bind(lip_engine_t* e, const float* theta, const float* consts, fl
     set_error("lip_engine_bind: buffers must be 16-byte aligned");
     return LIP_ERR_ARG;
   }
+  // re-binding only a (grown) workspace keeps the cached primal pass valid
+  if (e->theta != theta || e->consts != consts || e->prim != prim) e->primal_done = false;
   e->theta = theta; e->consts = consts; e->prim = prim; e->work = work;
   e->work_pp = work_floats_per_probe; e->max_chunk = max_probes_per_chunk;
-  e->primal_done = false;
   return LIP_OK;
 }
 

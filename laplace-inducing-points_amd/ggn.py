@@ -1,0 +1,220 @@
+"""GGN operators — same call surface as the reference's ``src/ggn.py``, computed by the HIP engine.
+
+``compute_ggn_vp`` (``src/ggn.py:97``), ``compute_W_vps`` (``:9``), ``compute_ggn_dense`` (``:149``),
+``build_WTW`` (``:198``), ``build_WTWz`` (``:233``), ``ensure_symmetry`` (``:277``).
+
+The reference returns closures that callers ``vmap`` over probe vectors.  A ctypes call cannot be
+vmapped, and every consumer is multi-vector anyway, so the closures here are *block operators*:
+called on ``(D,)`` they return ``(D,)``; called on ``(P, D)`` (rows = probes, the reference's
+``(S, D)`` / ``(P, D)`` layout, ``src/sample.py:151``, ``src/stochtrace.py:28``) they process the whole
+block in one engine call; ``.cols(M)`` takes the ``(D, k)`` column layout the reference uses when it
+calls an oracle on a matrix (``src/stochtrace.py:64,74,177``).  Inputs are never mutated; outputs are
+fresh float32 device tensors.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from .engine import LinearizedNet
+from .utils import flatten_nn_params
+
+_ENGINE_CACHE = {}
+_ENGINE_CACHE_MAX = 4
+
+
+def _leaves(tree):
+    if isinstance(tree, dict):
+        for k in sorted(tree):
+            yield from _leaves(tree[k])
+    else:
+        yield tree
+
+
+def get_engine(state, Z, model_type) -> LinearizedNet:
+    """One engine per (theta snapshot, Z snapshot, model_type); the factories of the reference
+    snapshot ``flat_params`` at factory time (``src/ggn.py:10,108``) — so does the cache key
+    (data pointers + in-place version counters)."""
+    key = (model_type, id(state.net), tuple(Z.shape), Z.data_ptr(), Z._version,
+           tuple((t.data_ptr(), t._version) for t in _leaves(state.params) if torch.is_tensor(t)),
+           tuple((t.data_ptr(), t._version) for t in _leaves(state.batch_stats) if torch.is_tensor(t)))
+    eng = _ENGINE_CACHE.get(key)
+    if eng is None:
+        eng = LinearizedNet(state, Z, model_type)
+        if len(_ENGINE_CACHE) >= _ENGINE_CACHE_MAX:
+            _ENGINE_CACHE.pop(next(iter(_ENGINE_CACHE)))
+        _ENGINE_CACHE[key] = eng
+        eng._keepalive = (state.params, state.batch_stats, Z)   # keep the keyed storage alive
+    return eng
+
+
+def clear_engine_cache():
+    _ENGINE_CACHE.clear()
+
+
+class BlockOperator:
+    """A linear map applied to one vector ``(n_in...)`` or to a block ``(P, n_in...)``."""
+
+    def __init__(self, fn_block, in_shape, out_shape, engine=None, tag=""):
+        self._fn, self.in_shape, self.out_shape = fn_block, tuple(in_shape), tuple(out_shape)
+        self.engine, self.tag = engine, tag
+
+    def __call__(self, v: torch.Tensor) -> torch.Tensor:
+        nd = len(self.in_shape)
+        if v.dim() == nd:
+            return self._fn(v[None])[0]
+        if v.dim() == nd + 1:
+            return self._fn(v)
+        raise ValueError(f"{self.tag}: expected shape {self.in_shape} or (P,)+{self.in_shape}, got {tuple(v.shape)}")
+
+    def rows(self, Mrows: torch.Tensor) -> torch.Tensor:      # (P, n_in) -> (P, n_out)
+        return self._fn(Mrows)
+
+    def cols(self, Mcols: torch.Tensor) -> torch.Tensor:      # (n_in, k) -> (n_out, k)
+        return self._fn(Mcols.T.contiguous()).T
+
+
+def _logvar(state):
+    return float(torch.as_tensor(state.params["logvar"]["logvar"]).detach().cpu())
+
+
+def compute_ggn_vp(state, Z, model_type, full_set_size=None):
+    """``src/ggn.py:97-146``: v -> (N/M) sum_i J_i^T H_i J_i v (x exp(-logvar) for the regressor,
+    ``:111-113``).  One fused tangent-forward -> output-Hessian -> backward sweep per probe block."""
+    eng = get_engine(state, Z, model_type)
+    M = Z.shape[0]
+    N = full_set_size or M
+    recal_term = N / M
+    if model_type == "regressor":
+        recal_term *= math.exp(-_logvar(state))
+    return BlockOperator(lambda V: eng.ggn_vp(V, recal_term, 0.0), (eng.D,), (eng.D,), eng, "ggn_vp")
+
+
+def compute_W_vps(state, Z, model_type, full_set_size=None, blockwise=False):
+    """``src/ggn.py:9-93``: square-root factors  W^T v = sqrt(N/M) [L_i^T J_i v]_i  (M, K)
+    and  W U = sqrt(N/M) sum_i J_i^T L_i U_i  (D,);  regressor: L = exp(-logvar/2), outputs squeezed
+    to (M,) as the reference does (``:58``)."""
+    eng = get_engine(state, Z, model_type)
+    M = Z.shape[0]
+    N = full_set_size or M
+    c = math.sqrt(N / M)
+    if model_type == "regressor":
+        c *= math.exp(-0.5 * _logvar(state))
+    K = eng.K
+    inner = (M,) if (model_type == "regressor" and K == 1) else (M, K)
+
+    def WT_block(V):
+        return eng.jvp(V, "lt", c).reshape((V.shape[0],) + inner)
+
+    def W_block(U):
+        return eng.vjp(U.reshape(U.shape[0], M, K), "l", c)
+
+    WTfun = BlockOperator(WT_block, (eng.D,), inner, eng, "WTfun")
+    Wfun = BlockOperator(W_block, inner, (eng.D,), eng, "Wfun")
+    if not blockwise:
+        return Wfun, WTfun
+
+    kshape = () if inner == (M,) else (K,)
+
+    def WT_point(i, v):                      # (D,) -> (K,)     src/ggn.py:55-62
+        return WTfun(v)[..., i] if inner == (M,) else WTfun(v)[..., i, :]
+
+    def W_point(i, U_i):                     # (K,) -> (D,)     src/ggn.py:64-76
+        U_i = torch.as_tensor(U_i, device=eng.device, dtype=torch.float32)
+        batch = U_i.shape[:U_i.dim() - len(kshape)]
+        U = torch.zeros(tuple(batch) + inner, device=eng.device, dtype=torch.float32)
+        if inner == (M,):
+            U[..., i] = U_i
+        else:
+            U[..., i, :] = U_i
+        return Wfun(U)
+
+    return W_point, WT_point
+
+
+def compute_ggn_dense(state, Z, model_type, full_set_size=None, block: int = 256):
+    """``src/ggn.py:149-193``: the dense GGN, returned as ``(GGN, flat_params, unravel_fn)``.  Built by
+    applying the matrix-free operator to identity blocks (toy sizes only: D^2 floats)."""
+    flat_params, unravel_fn = flatten_nn_params(state.params)
+    vp = compute_ggn_vp(state, Z, model_type, full_set_size=full_set_size)
+    eng = vp.engine
+    D = eng.D
+    GGN = torch.empty(D, D, device=eng.device, dtype=torch.float32)
+    for s in range(0, D, block):
+        e = min(D, s + block)
+        I = torch.zeros(e - s, D, device=eng.device, dtype=torch.float32)
+        I[torch.arange(e - s), torch.arange(s, e)] = 1.0
+        GGN[s:e] = vp(I)                       # rows of a symmetric matrix
+    return GGN, flat_params.to(eng.device), unravel_fn
+
+
+def _apply_block(fun, E):
+    return fun.rows(E) if isinstance(fun, BlockOperator) else torch.stack([fun(e) for e in E])
+
+
+def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
+    """``src/ggn.py:198-227``: dense W^T W (d, d), symmetrised through its upper triangle (``:227``).
+
+    ``block`` only bounds peak memory in the reference (column blocks under ``jax.remat``); here it is a
+    lower bound on the batch handed to the engine — the result does not depend on it.  When W and W^T
+    come from one engine the Gram is formed as  Wm Wm^T  from the materialised factor Wm = W(I_d)
+    (d engine rows + one plain GEMM) instead of d x (W then W^T) network sweeps."""
+    inner_shape = tuple(inner_shape)
+    if isinstance(W, BlockOperator) and W.engine is not None:
+        dev = W.engine.device
+        D = W.engine.D
+        bs = max(int(block), min(d, max(1, (1 << 30) // (4 * D))))
+        if d * D * 4 <= (8 << 30):
+            Wm = torch.empty(d, D, device=dev, dtype=torch.float32)
+            for s in range(0, d, bs):
+                e = min(d, s + bs)
+                E = torch.zeros(e - s, d, device=dev, dtype=torch.float32)
+                E[torch.arange(e - s), torch.arange(s, e)] = 1.0
+                Wm[s:e] = W.rows(E.reshape((e - s,) + inner_shape))
+            WTW = (Wm @ Wm.T)
+        else:
+            WTW = torch.empty(d, d, device=dev, dtype=torch.float32)
+            for s in range(0, d, bs):
+                e = min(d, s + bs)
+                E = torch.zeros(e - s, d, device=dev, dtype=torch.float32)
+                E[torch.arange(e - s), torch.arange(s, e)] = 1.0
+                WTW[:, s:e] = WT.rows(W.rows(E.reshape((e - s,) + inner_shape))).reshape(e - s, d).T
+    else:
+        cols = []
+        for j in range(d):
+            e = torch.zeros(d, dtype=dtype)
+            e[j] = 1.0
+            cols.append(WT(W(e.reshape(inner_shape))).reshape(-1))
+        WTW = torch.stack(cols, dim=1)
+    WTW = WTW.to(dtype)
+    return torch.triu(WTW) + torch.triu(WTW, 1).T
+
+
+def build_WTWz(WT, W_z, inner_shape_z, *, d, dtype=torch.float32, block=64):
+    """``src/ggn.py:233-272``: cross-Gram W^T W_z (d, d_z)."""
+    inner_shape_z = tuple(inner_shape_z)
+    d_z = math.prod(inner_shape_z)
+    if isinstance(W_z, BlockOperator) and W_z.engine is not None:
+        dev = W_z.engine.device
+        D = W_z.engine.D
+        bs = max(int(block), min(d_z, max(1, (1 << 30) // (4 * D))))
+        G = torch.empty(d, d_z, device=dev, dtype=torch.float32)
+        for s in range(0, d_z, bs):
+            e = min(d_z, s + bs)
+            E = torch.zeros(e - s, d_z, device=dev, dtype=torch.float32)
+            E[torch.arange(e - s), torch.arange(s, e)] = 1.0
+            G[:, s:e] = _apply_block(WT, W_z.rows(E.reshape((e - s,) + inner_shape_z))).reshape(e - s, d).T
+        return G.to(dtype)
+    cols = []
+    for j in range(d_z):
+        e = torch.zeros(d_z, dtype=dtype)
+        e[j] = 1.0
+        cols.append(WT(W_z(e.reshape(inner_shape_z))).reshape(-1))
+    return torch.stack(cols, dim=1).to(dtype)
+
+
+def ensure_symmetry(M, jitter=1e-8):
+    """``src/ggn.py:277-278``."""
+    return 0.5 * (M + M.T) + jitter * torch.eye(M.shape[0], dtype=M.dtype, device=M.device)

@@ -1,0 +1,163 @@
+"""Host drivers of the Krylov recurrences over the HIP primitives (``csrc/lip_krylov.hip``).
+
+All vectors are blocks ``(P, N)`` of float32 on the GPU: P independent recurrences advance in lock
+step, the small (k x k) / per-probe scalars stay on the device, and the only host synchronisation is
+CG's convergence poll.
+
+``lanczos_tridiag`` + ``funm_lanczos_sym`` restate matfree's ``decomp.tridiag_sym`` /
+``funm.funm_lanczos_sym`` as the reference calls them (``src/sample.py:113-115,126``):
+k-step Lanczos from b/||b|| with full re-orthogonalisation (blocked classical Gram-Schmidt applied
+twice = two GEMV passes over Q), f(A) b ~= ||b|| Q^T f(T) e1.  ``cg`` restates
+``jax.scipy.sparse.linalg.cg`` with its defaults (``src/stochtrace.py:146,192``, ``src/sample.py:71``).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import _native as nv
+
+
+def _chk(X: torch.Tensor) -> torch.Tensor:
+    if not (X.is_cuda and X.dtype == torch.float32 and X.is_contiguous()):
+        raise nv.NativeError("Krylov primitives take contiguous float32 CUDA blocks (no CPU fallback)")
+    return X
+
+
+def bdot(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """out[p] = <X[p], Y[p]>"""
+    lib = nv.load()
+    P, N = _chk(X).shape
+    out = torch.empty(P, device=X.device, dtype=torch.float32)
+    nv.check(lib.lip_bdot(nv.ptr(X), nv.ptr(_chk(Y)), nv.ptr(out), P, N, nv.stream_ptr()), "lip_bdot")
+    return out
+
+
+def axpby(Y, X, a: Optional[torch.Tensor] = None, a_s: float = 1.0, b: Optional[torch.Tensor] = None, b_s: float = 1.0):
+    """in place: Y[p] = (a_s a[p]) X[p] + (b_s b[p]) Y[p]"""
+    lib = nv.load()
+    P, N = _chk(Y).shape
+    nv.check(lib.lip_axpby(nv.ptr(Y), nv.ptr(_chk(X)), nv.ptr(a), float(a_s), nv.ptr(b), float(b_s), P, N,
+                           nv.stream_ptr()), "lip_axpby")
+    return Y
+
+
+def fill_rademacher(P: int, N: int, seed: int, device="cuda") -> torch.Tensor:
+    lib = nv.load()
+    X = torch.empty(P, N, device=device, dtype=torch.float32)
+    nv.check(lib.lip_fill_rademacher(nv.ptr(X), P, N, int(seed) & (2 ** 64 - 1), nv.stream_ptr()), "lip_fill_rademacher")
+    return X
+
+
+def fill_normal(P: int, N: int, seed: int, device="cuda") -> torch.Tensor:
+    lib = nv.load()
+    X = torch.empty(P, N, device=device, dtype=torch.float32)
+    nv.check(lib.lip_fill_normal(nv.ptr(X), P, N, int(seed) & (2 ** 64 - 1), nv.stream_ptr()), "lip_fill_normal")
+    return X
+
+
+def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Tensor, k: int
+                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """k-step Lanczos with full re-orthogonalisation, P recurrences at once.
+
+    ``matvec`` maps a (P, N) block to a (P, N) block.  Returns Q (P, k, N) with orthonormal rows,
+    diag (P, k), offdiag (P, k-1).  Bytes per step j (fp32): (7 + 4 (j+1)) N x 4 per probe."""
+    lib = nv.load()
+    P, N = _chk(V0).shape
+    if k > N:
+        raise ValueError(f"num_matvecs={k} exceeds dimension {N}")
+    st = nv.stream_ptr()
+    dev = V0.device
+    Q = torch.empty(P, k, N, device=dev, dtype=torch.float32)
+    diag = torch.zeros(P, k, device=dev, dtype=torch.float32)
+    off = torch.zeros(P, max(k - 1, 0), device=dev, dtype=torch.float32)
+    c1 = torch.empty(P, k, device=dev, dtype=torch.float32)
+    c2 = torch.empty(P, k, device=dev, dtype=torch.float32)
+    nrm2 = bdot(V0, V0)
+    nv.check(lib.lip_scale_store(nv.ptr(V0), nv.ptr(nrm2), nv.ptr(Q), 0, P, k, N, st), "lip_scale_store")
+    for j in range(k):
+        w = matvec(Q[:, j].contiguous()).contiguous()
+        _chk(w)
+        nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c1), P, j + 1, k, N, st), "lip_multi_dot")
+        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c1), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, st), "lip_multi_axpy_norm")
+        nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c2), P, j + 1, k, N, st), "lip_multi_dot")
+        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c2), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, st), "lip_multi_axpy_norm")
+        diag[:, j] = c1[:, j] + c2[:, j]
+        if j + 1 < k:
+            off[:, j] = torch.sqrt(nrm2)
+            nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(nrm2), nv.ptr(Q), j + 1, P, k, N, st), "lip_scale_store")
+    return Q, diag, off
+
+
+def tridiag_dense(diag: torch.Tensor, off: torch.Tensor) -> torch.Tensor:
+    T = torch.diag_embed(diag)
+    if off.shape[-1] > 0:
+        T = T + torch.diag_embed(off, 1) + torch.diag_embed(off, -1)
+    return T
+
+
+def dense_funm_sym_eigh(matfun: Callable, clip_min: Optional[float] = None):
+    """Dense f(T) through eigh; ``clip_min=1.0`` reproduces the reference's monkey-patch
+    (``src/matfree_monkeypatch.py:8-22``, clip at ``:19``).  Batched over leading dimensions."""
+    def fun(T):
+        ev, U = torch.linalg.eigh(T)
+        if clip_min is not None:
+            ev = torch.clamp(ev, min=clip_min)
+        return (U * matfun(ev).unsqueeze(-2)) @ U.transpose(-1, -2)
+    return fun
+
+
+def funm_lanczos_sym(dense_funm: Callable, num_matvecs: int):
+    """``estimate(matvec, B)`` ~= f(A) B[p] for every row of the block B (P, N)."""
+    lib = nv.load()
+
+    def estimate(matvec, B):
+        B = _chk(B.contiguous())
+        P, N = B.shape
+        k = int(num_matvecs)
+        length = torch.sqrt(bdot(B, B))
+        Q, diag, off = lanczos_tridiag(matvec, B, k)
+        fT = dense_funm(tridiag_dense(diag.double(), off.double()))
+        coef = (-(fT[:, :, 0] * length.double()[:, None])).float().contiguous()      # (P, k)
+        out = torch.zeros(P, N, device=B.device, dtype=torch.float32)
+        nrm = torch.empty(P, device=B.device, dtype=torch.float32)
+        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(coef), nv.ptr(out), nv.ptr(nrm), P, k, k, N, nv.stream_ptr()),
+                 "lip_multi_axpy_norm")
+        return out
+
+    return estimate
+
+
+def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[torch.Tensor] = None, tol: float = 1e-5,
+       atol: float = 0.0, maxiter: Optional[int] = None, check_every: int = 1):
+    """Batched conjugate gradients, one independent solve per row of B (P, N), with JAX's defaults and
+    stopping rule (||r||^2 <= max(tol^2 ||b||^2, atol^2), maxiter = 10 N).  Returns ``(X, info)`` where
+    info holds the iteration count and final residual norms (the reference discards it)."""
+    lib = nv.load()
+    B = _chk(B.contiguous())
+    P, N = B.shape
+    st = nv.stream_ptr()
+    if maxiter is None:
+        maxiter = 10 * N
+    X = torch.zeros_like(B) if x0 is None else _chk(x0.clone().contiguous())
+    R = B.clone() if x0 is None else (B - A(X)).contiguous()
+    Pd = R.clone()
+    rr = bdot(R, R)
+    atol2 = torch.clamp(tol * tol * bdot(B, B), min=atol * atol)
+    active = (rr > atol2).to(torch.int32)
+    rr_new = torch.empty_like(rr)
+    it = 0
+    while it < maxiter:
+        if it % check_every == 0 and not bool(active.any()):
+            break
+        Ap = _chk(A(Pd).contiguous())
+        pAp = bdot(Pd, Ap)
+        nv.check(lib.lip_cg_update(nv.ptr(X), nv.ptr(R), nv.ptr(Pd), nv.ptr(Ap), nv.ptr(rr), nv.ptr(pAp), nv.ptr(active),
+                                   nv.ptr(rr_new), P, N, st), "lip_cg_update")
+        nv.check(lib.lip_cg_direction(nv.ptr(Pd), nv.ptr(R), nv.ptr(rr_new), nv.ptr(rr), nv.ptr(active), P, N, st),
+                 "lip_cg_direction")
+        rr = torch.where(active.bool(), rr_new, rr)
+        active = (rr > atol2).to(torch.int32) * active
+        it += 1
+    return X, dict(iterations=it, residual_norm=torch.sqrt(rr))

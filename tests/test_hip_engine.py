@@ -1,0 +1,129 @@
+"""GPU parity of the HIP engine against the CPU oracle / tape emulator (fp32 vs float64).
+
+Tolerance: the kernels compute exact-f32 GEMMs (v_mfma_f32_32x32x2_f32 == fmaf chain) with f32
+accumulation, so errors are O(1e-7 * sum|a*b|); the tests bound max|err| <= 2e-4 * max|ref|
+(and 5e-5 for the small toy nets), stated here per BASELINE.json's "fp32 tolerance".
+"""
+import math
+
+import pytest
+import torch
+
+from lip_amd import _native as nv
+from lip_amd.engine import LinearizedNet, build_consts
+from lip_amd.scalemodels import LargeClassifier, ResNet1M
+from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
+from lip_amd.utils import flatten_nn_params
+from tape_emulator import TapeMachine
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _cases():
+    g = torch.Generator().manual_seed(0)
+    return {
+        "sine_regressor": (SimpleRegressor(8, 4), torch.randn(16, 1, dtype=F64, generator=g), "regressor", 7),
+        "xor_classifier": (SimpleClassifier(16, 2, 2), torch.randn(32, 2, dtype=F64, generator=g), "classifier", 5),
+        "mlp_ragged": (LargeClassifier((6, 6, 1), [40, 24], 2, 5), torch.rand(9, 6, 6, 1, dtype=F64, generator=g),
+                       "classifier", 3),
+        "mlp_wide": (LargeClassifier((12, 12, 1), [200, 136, 72], 3, 10), torch.rand(50, 12, 12, 1, dtype=F64, generator=g),
+                     "classifier", 4),
+        "resnet_tiny": (ResNet1M(4, input_shape=(8, 8, 3), widths=(4, 8, 12), blocks_per_stage=2),
+                        torch.rand(3, 8, 8, 3, dtype=F64, generator=g), "classifier", 2),
+        "resnet_small": (ResNet1M(10, input_shape=(16, 16, 3), widths=(32, 64, 128), blocks_per_stage=1),
+                         torch.rand(5, 16, 16, 3, dtype=F64, generator=g), "classifier", 3),
+    }
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _localise(eng, tm, V, U, P, mode, c, which_list):
+    """Run both machines op by op and report the first op whose outputs differ."""
+    msgs = []
+    Vd = V.float().cuda().contiguous()
+    Yd = torch.zeros(P, eng.D, device="cuda")
+    Hd = (U.float().cuda().contiguous() if U is not None else torch.zeros(P, eng.n * eng.K, device="cuda"))
+    eng.work.zero_()
+    tm.work.zero_()
+    tm.V = V.to(F64).contiguous().reshape(-1)
+    tm.Y = torch.zeros(P * eng.D, dtype=F64)
+    tm.H = (U.to(F64).contiguous().reshape(-1) if U is not None else torch.zeros(P * eng.n * eng.K, dtype=F64))
+    for which in which_list:
+        for i, op in enumerate(eng.cn.tapes[which]):
+            if which == 2 and op.kind == nv.OP_HEAD and mode == nv.HEAD_GGN:
+                continue
+            nv.check(eng.lib.lip_debug_run_ops(eng.h, which, i, 1, nv.ptr(Vd), nv.ptr(Yd), nv.ptr(Hd), P, mode, c,
+                                               nv.stream_ptr()), "debug_run_ops")
+            torch.cuda.synchronize()
+            tm.run_op(op, P, mode, c)
+            for name, dev, ref in (("work", eng.work, tm.work), ("Y", Yd.reshape(-1), tm.Y), ("H", Hd.reshape(-1), tm.H)):
+                err = (dev.double().cpu() - ref).abs().max().item()
+                scale = ref.abs().max().item() + 1e-30
+                if not (err <= 2e-4 * scale):
+                    msgs.append(f"tape {which} op {i} kind {op.kind}: {name} max err {err:.3e} (scale {scale:.3e})")
+            if msgs:
+                return msgs
+    return msgs
+
+
+@pytest.mark.parametrize("name", list(_cases().keys()))
+def test_engine_matches_tape_semantics(name):
+    net, Z, model_type, P = _cases()[name]
+    state = create_state(net, 3, dtype=F64, logvar=-0.3)
+    eng = LinearizedNet(state, Z, model_type, workspace_bytes=1 << 28, max_chunk=P)
+    torch.cuda.synchronize()
+    flat, _ = flatten_nn_params(state.params)
+    consts = build_consts(eng.cn, state.params, state.batch_stats, "cpu", F64)
+    tm = TapeMachine(eng.cn, flat, consts, Z, chunk=eng.chunk)
+    tm.primal()
+    tol = 2e-4
+    # primal cache
+    perr = (eng.prim.double().cpu() - tm.prim).abs().max().item()
+    assert perr <= tol * tm.prim.abs().max().item(), f"primal cache differs: {perr}"
+
+    g = torch.Generator().manual_seed(1)
+    V = torch.randn(P, eng.D, dtype=F64, generator=g)
+    U = torch.randn(P, eng.n, eng.K, dtype=F64, generator=g)
+    n = Z.shape[0]
+    scale = 2.5 * (math.exp(0.3) if model_type == "regressor" else 1.0)
+    Y = eng.ggn_vp(V, scale, 0.37)
+    Yr = tm.ggn_vp(V, scale, 0.37)
+    Uh = eng.jvp(V, "lt", 1.3)
+    Ur = tm.jvp(V, nv.HEAD_LT, 1.3)
+    Yw = eng.vjp(U, "l", 0.7)
+    Ywr = tm.vjp(U, nv.HEAD_L, 0.7)
+    Jr = eng.jvp(V, "raw")
+    Jrr = tm.jvp(V, nv.HEAD_OUT, 1.0)
+    Jt = eng.vjp(U, "raw")
+    Jtr = tm.vjp(U, nv.HEAD_IN, 1.0)
+    torch.cuda.synchronize()
+    errs = dict(ggn=_rel(Y, Yr), wt=_rel(Uh, Ur), w=_rel(Yw, Ywr), jvp=_rel(Jr, Jrr), vjp=_rel(Jt, Jtr))
+    bad = {k: v for k, v in errs.items() if not (v <= tol)}
+    if bad:
+        msgs = _localise(eng, tm, V, None, P, nv.HEAD_GGN, scale, [1, 2])
+        pytest.fail(f"{name}: {bad}; first differing op: {msgs}")
+
+
+def test_probe_chunking_and_single_vector():
+    """P larger than the workspace chunk, and a plain (D,) vector, give the same answers."""
+    net, Z, model_type, _ = _cases()["mlp_ragged"]
+    state = create_state(net, 3, dtype=F64)
+    big = LinearizedNet(state, Z, model_type, max_chunk=16)
+    small = LinearizedNet(state, Z, model_type, max_chunk=3)
+    V = torch.randn(7, big.D, generator=torch.Generator().manual_seed(5)).cuda()
+    a = big.ggn_vp(V, 1.0, 0.1)
+    b = small.ggn_vp(V, 1.0, 0.1)
+    c = big.ggn_vp(V[2], 1.0, 0.1)
+    torch.cuda.synchronize()
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a[2], c[0], rtol=1e-4, atol=1e-5)   # split-K atomics reorder the sum
+
+
+def test_missing_netspec_fails_loudly():
+    from lip_amd.utils import TrainState
+    st = TrainState(params={"params": {"W": torch.ones(1, 1)}}, apply_fn=lambda p, x, **k: x)
+    with pytest.raises(TypeError):
+        LinearizedNet(st, torch.zeros(2, 1), "regressor")

@@ -1,0 +1,93 @@
+"""GPU parity of the Krylov / trace primitives (lip_krylov.hip) against float64 torch."""
+import ctypes as C
+
+import pytest
+import torch
+
+from lip_amd import _native as nv
+
+pytestmark = pytest.mark.gpu
+
+
+def _blk(P, N, seed):
+    return torch.randn(P, N, generator=torch.Generator().manual_seed(seed)).cuda()
+
+
+@pytest.mark.parametrize("P,N", [(1, 1), (3, 241), (4, 1027), (5, 100003), (2, 1084586)])
+def test_bdot_axpby(P, N):
+    lib = nv.load()
+    X, Y = _blk(P, N, 1), _blk(P, N, 2)
+    out = torch.empty(P, device="cuda")
+    nv.check(lib.lip_bdot(nv.ptr(X), nv.ptr(Y), nv.ptr(out), P, N, nv.stream_ptr()), "bdot")
+    ref = (X.double() * Y.double()).sum(1)
+    assert torch.allclose(out.double(), ref, rtol=2e-5, atol=1e-3 * (N ** 0.5) * 1e-2)
+    a = torch.rand(P, device="cuda") + 0.5
+    b = torch.rand(P, device="cuda") - 0.5
+    Y2 = Y.clone()
+    nv.check(lib.lip_axpby(nv.ptr(Y2), nv.ptr(X), nv.ptr(a), 2.0, nv.ptr(b), -1.0, P, N, nv.stream_ptr()), "axpby")
+    ref2 = 2.0 * a[:, None] * X - b[:, None] * Y
+    assert torch.allclose(Y2, ref2, rtol=1e-5, atol=1e-5)
+    # b_s == 0: Y may hold NaN garbage
+    Y3 = torch.full_like(Y, float("nan"))
+    nv.check(lib.lip_axpby(nv.ptr(Y3), nv.ptr(X), 0, 3.0, 0, 0.0, P, N, nv.stream_ptr()), "axpby copy")
+    assert torch.allclose(Y3, 3.0 * X)
+
+
+@pytest.mark.parametrize("P,k,kmax,N", [(2, 1, 4, 500), (3, 7, 9, 4099), (2, 33, 40, 70001)])
+def test_lanczos_primitives(P, k, kmax, N):
+    lib = nv.load()
+    Q = _blk(P * kmax, N, 3).reshape(P, kmax, N).contiguous()
+    w = _blk(P, N, 4)
+    c = torch.full((P, kmax), 7.0, device="cuda")
+    nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c), P, k, kmax, N, nv.stream_ptr()), "multi_dot")
+    ref = torch.einsum("pkn,pn->pk", Q[:, :k].double(), w.double())
+    assert torch.allclose(c[:, :k].double(), ref, rtol=1e-4, atol=1e-2)
+    assert torch.all(c[:, k:] == 7.0)
+    w2 = w.clone()
+    nrm = torch.empty(P, device="cuda")
+    nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c), nv.ptr(w2), nv.ptr(nrm), P, k, kmax, N, nv.stream_ptr()), "maxpy")
+    refw = w.double() - torch.einsum("pk,pkn->pn", c[:, :k].double(), Q[:, :k].double())
+    assert torch.allclose(w2.double(), refw, rtol=1e-4, atol=1e-2 * refw.abs().max().item() * 1e-2)
+    assert torch.allclose(nrm.double(), (w2.double() ** 2).sum(1), rtol=1e-4)
+    j = k - 1
+    nv.check(lib.lip_scale_store(nv.ptr(w2), nv.ptr(nrm), nv.ptr(Q), j, P, kmax, N, nv.stream_ptr()), "scale_store")
+    assert torch.allclose(Q[:, j], w2 / nrm.sqrt()[:, None], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("P,N", [(3, 1027), (2, 250001)])
+def test_cg_primitives(P, N):
+    lib = nv.load()
+    x, r, p, Ap = (_blk(P, N, s) for s in (5, 6, 7, 8))
+    rr_old = (r.double() ** 2).sum(1).float()
+    pAp = torch.rand(P, device="cuda") + 1.0
+    active = torch.tensor([1, 0, 1][:P], dtype=torch.int32, device="cuda")
+    x0, r0 = x.clone(), r.clone()
+    rr_new = torch.empty(P, device="cuda")
+    nv.check(lib.lip_cg_update(nv.ptr(x), nv.ptr(r), nv.ptr(p), nv.ptr(Ap), nv.ptr(rr_old), nv.ptr(pAp), nv.ptr(active),
+                               nv.ptr(rr_new), P, N, nv.stream_ptr()), "cg_update")
+    a = (rr_old / pAp)[:, None]
+    act = active.bool()[:, None]
+    assert torch.allclose(x, torch.where(act, x0 + a * p, x0), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(r, torch.where(act, r0 - a * Ap, r0), rtol=1e-5, atol=1e-5)
+    ref_rr = (r.double() ** 2).sum(1)
+    assert torch.allclose(rr_new.double()[active.bool()], ref_rr[active.bool()], rtol=1e-4)
+    p0 = p.clone()
+    nv.check(lib.lip_cg_direction(nv.ptr(p), nv.ptr(r), nv.ptr(rr_new), nv.ptr(rr_old), nv.ptr(active), P, N,
+                                  nv.stream_ptr()), "cg_direction")
+    beta = (rr_new / rr_old)[:, None]
+    assert torch.allclose(p, torch.where(act, r + beta * p0, p0), rtol=1e-5, atol=1e-5)
+
+
+def test_fill_statistics_and_determinism():
+    lib = nv.load()
+    P, N = 4, 100003
+    A, B = torch.empty(P, N, device="cuda"), torch.empty(P, N, device="cuda")
+    nv.check(lib.lip_fill_rademacher(nv.ptr(A), P, N, 1234, nv.stream_ptr()), "rademacher")
+    nv.check(lib.lip_fill_rademacher(nv.ptr(B), P, N, 1234, nv.stream_ptr()), "rademacher")
+    assert torch.equal(A, B) and torch.all(A.abs() == 1.0)
+    assert abs(A.mean().item()) < 0.01
+    nv.check(lib.lip_fill_rademacher(nv.ptr(B), P, N, 1235, nv.stream_ptr()), "rademacher")
+    assert (A != B).float().mean().item() > 0.4
+    nv.check(lib.lip_fill_normal(nv.ptr(A), P, N, 99, nv.stream_ptr()), "normal")
+    assert abs(A.mean().item()) < 0.01 and abs(A.std().item() - 1.0) < 0.01
+    assert abs((A ** 4).mean().item() - 3.0) < 0.1
