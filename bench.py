@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py — GGN-vector products/s (and posterior samples/s) of the MI355X-native engine.
+
+Workload (BASELINE.json configs[3]): CIFAR-CNN `ResNet1M` (D = 1 084 586,
+162 366 720 MACs/example), synthetic inputs X ~ U[0,1]^(n x 32 x 32 x 3) with n = 50 inducing points
+per GPU, seeded random-init weights + BN statistics, P = 256 Rademacher probes, alpha = 0.005,
+full_set_size = 49 000.  One *step* = one block matvec  V (P, D) -> (GGN + alpha I) V  over the rank's
+data slice, followed (N > 1) by ONE all-reduce of the (P, D) block — the data sum shards across ranks
+(weak scaling: every rank holds its own 50-example slice).  `value` = P * N * steps / time, i.e.
+GGN-vector products per second counted per 50-example data shard, inputs resident in HBM.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import lip_amd  # noqa: E402,F401
+from lip_amd import _native as nv  # noqa: E402
+from lip_amd import krylov  # noqa: E402
+from lip_amd.dist import ShardedDataSum  # noqa: E402
+from lip_amd.engine import LinearizedNet  # noqa: E402
+from lip_amd.scalemodels import ResNet1M  # noqa: E402
+from lip_amd.toymodels import create_state  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(net, n, seconds_budget=25.0):
+    """The CPU restatement (oracle, PyTorch fp32, literal per-example jvp -> H -> vjp of src/ggn.py:133-144)
+    timed on this box's host cores, on a bounded sample of the same workload."""
+    from oracle.ggn import compute_ggn_vp as oracle_ggn_vp
+    st = create_state(net, seed=1231231234, dtype=torch.float32)
+    g = torch.Generator().manual_seed(7)
+    n_s = min(n, 8)                                       # bounded sample: 8 of the 50 examples, 1 probe
+    Z = torch.rand((n_s,) + tuple(net.input_shape_raw), generator=g)
+    D = sum(t.numel() for t in _leaves(st.params["params"]))
+    v = torch.randn(D, generator=g)
+    vp = oracle_ggn_vp(st, Z, "classifier", full_set_size=49000)
+    vp(v)                                                 # warm-up
+    t0, reps = time.perf_counter(), 0
+    while reps < 1 or (time.perf_counter() - t0 < seconds_budget and reps < 5):
+        vp(v)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    per_example_probe = dt / n_s
+    return dict(value=1.0 / (per_example_probe * n), unit="GGN-vp/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{reps} x (1 probe x {n_s} of {n} examples), literal per-example jvp->H->vjp in PyTorch fp32 "
+                       f"on CPU (CPU restatement, not reference JAX); rate extrapolated linearly to n={n}")
+
+
+def _leaves(tree):
+    if isinstance(tree, dict):
+        for v in tree.values():
+            yield from _leaves(v)
+    else:
+        yield tree
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--probes", type=int, default=256)
+    ap.add_argument("--n", type=int, default=50, help="examples (inducing points) per GPU")
+    ap.add_argument("--samples", type=int, default=200, help="posterior samples for the samples/s line (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    net = ResNet1M(10)
+    state = create_state(net, seed=1231231234, dtype=torch.float32)           # config/scale/resnet1_cifar10.yml:5
+    g = torch.Generator().manual_seed(280300 + rank)                          # ip.seed (+rank: own data slice)
+    Z = torch.rand(args.n, 32, 32, 3, generator=g)
+    P, n, alpha, full = args.probes, args.n, 0.005, 49000
+    n_total = n * world
+    eng = LinearizedNet(state, Z.to(dev), "classifier", device=dev, workspace_bytes=24 << 30, max_chunk=P)
+    scale = full / n_total
+    op = ShardedDataSum(lambda V: eng.ggn_vp(V, scale, 0.0), alpha)
+    V = krylov.fill_rademacher(P, eng.D, 1234, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        op(V)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        Y = op(V)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = P * world * args.steps / dt
+
+    # ---- live per-kernel figure: HIP events on the launch stream, instrumented extra steps -------------
+    eng.profile(True)
+    prof_steps = max(1, min(3, args.steps))
+    for _ in range(prof_steps):
+        eng.ggn_vp(V, scale, alpha)
+    prof = eng.profile_read()
+    eng.profile(False)
+    flops = eng.flops_per_probe()
+    kinds = {nv.OP_IGEMM: "igemm_kernel", nv.OP_WGRAD: "wgrad_kernel"}
+    per_kernel = {}
+    for k, name in kinds.items():
+        ms, cnt = prof.get(k, (0.0, 0))
+        if cnt:
+            per_kernel[name] = dict(ms_per_step=ms / prof_steps, launches_per_step=cnt // prof_steps,
+                                    avg_launch_ms=ms / cnt,
+                                    tflops=flops[k] * P * prof_steps / (ms * 1e-3) / 1e12)
+    other_ms = sum(ms for k, (ms, c) in prof.items() if k not in kinds) / prof_steps
+    dom = "igemm_kernel"
+    achieved = per_kernel[dom]["tflops"]
+    roofline = dict(bound="mfma", kernel=dom + " (tangent-forward + data-gradient implicit GEMMs, f32 MFMA)",
+                    achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TFLOPS,
+                    traffic=None, per_kernel=per_kernel, other_kernels_ms_per_step=other_ms,
+                    whole_sweep_tflops=sum(flops.values()) * P / (ms_per_step * 1e-3) / 1e12,
+                    flop_model="algorithmic FLOPs from the op tapes: conv segment 2*R*N*Ktot, data-gradient segment "
+                               "2*MACs of its conv, WGRAD 2*R*N*M (= 8*MACs_fwd per example-probe minus the input "
+                               "layer's two absent terms, SURVEY 8d)")
+
+    # ---- posterior samples/s (single-rank figure; reference algorithm src/sample.py:55-156) -----------
+    samples_line = None
+    if args.samples > 0 and rank == 0:
+        from lip_amd.sample import sample
+        st_dev = state.to(device=dev, dtype=torch.float32)
+        Zd = Z.to(dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        S = sample(st_dev, Zd, eng.D, alpha, 1392, "classifier", num_samples=args.samples, full_set_size=full)
+        torch.cuda.synchronize()
+        ts = time.perf_counter() - t1
+        samples_line = dict(value=args.samples / ts, unit="posterior samples/s", num_samples=args.samples,
+                            seconds=ts, includes="W^T W Gram build + 2M-step small-space Lanczos + W^T / W sweeps",
+                            finite=bool(torch.isfinite(S).all().item()))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(net, n)
+
+    if rank == 0:
+        line = dict(metric="GGN-vector products/sec", value=value, unit="GGN-vp/s", n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload="CIFAR-CNN ResNet1M GGN-vp (BASELINE configs[3]): D=1084586, "
+                                         f"n={n} examples/GPU, P={P} Rademacher probes/block, alpha=0.005, "
+                                         "full_set_size=49000; data sum sharded over ranks, one all-reduce per matvec",
+                                examples_per_gpu=n, probes=P, D=eng.D, probe_chunk=eng.chunk,
+                                parallelism=f"data-shard x{world}"),
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line,
+                    checksum=float(Y.double().abs().mean().item()))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,12 @@ int lip_engine_bind(lip_engine_t* e, const float* theta, const float* consts, fl
 /* run the primal tape once (caches activations, BN-normalised values, act', softmax).   */
 int lip_engine_primal(lip_engine_t* e, void* stream);
 
+/* measurement hook: when enabled every op launch is bracketed by HIP events recorded on the launch
+ * stream; lip_engine_profile_read sums elapsed ms and launch counts per op kind (index = LIP_OP_*)
+ * and clears the log.  Used by bench.py for the live per-kernel roofline figure.                 */
+int lip_engine_profile(lip_engine_t* e, int32_t enable);
+int lip_engine_profile_read(lip_engine_t* e, double* ms_by_kind, int64_t* launches_by_kind, int32_t nkinds);
+
 /* test hook: run ops [first, first+count) of one tape on a single probe chunk (P <= chunk size) */
 int lip_debug_run_ops(lip_engine_t* e, int32_t which, int32_t first, int32_t count, const float* V, float* Y,
                       float* H, int32_t P, int32_t head_mode, float head_c, void* stream);

@@ -58,6 +58,8 @@ SIGNATURES = {
     "lip_engine_set_tape": (C.c_int, [_V, C.c_int32, C.POINTER(Op), C.c_int32]),
     "lip_engine_bind": (C.c_int, [_V, _V, _V, _V, _V, C.c_int64, C.c_int32]),
     "lip_engine_primal": (C.c_int, [_V, _V]),
+    "lip_engine_profile": (C.c_int, [_V, C.c_int32]),
+    "lip_engine_profile_read": (C.c_int, [_V, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
     "lip_debug_run_ops": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, C.c_int32, C.c_int32,
                                     C.c_float, _V]),
     "lip_ggn_vp": (C.c_int, [_V, _V, _V, C.c_int32, C.c_float, C.c_float, _V]),
@@ -86,6 +88,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (libamdhip64 of its ROCm build).  It must be the one resident in
+    # the process before liblip_hip.so is opened, otherwise the library binds the system runtime and the
+    # two disagree about devices ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -37,6 +37,11 @@ struct lip_engine {
   int64_t work_pp = 0;      // workspace floats per probe
   int32_t max_chunk = 0;    // probes per chunk
   bool primal_done = false;
+  // optional per-op timing (HIP events recorded on the launch stream)
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<int> ev_kind;   // kind of the op bracketed by events (2i, 2i+1)
 };
 
 namespace {
@@ -81,8 +86,7 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
   switch (op.kind) {
     case LIP_OP_IGEMM: {
       if (op.nseg < 1 || op.nseg > 3) { set_error("IGEMM: nseg=%d", op.nseg); return LIP_ERR_ARG; }
-      IgemmP p;
-      memset(&p, 0, sizeof(p));
+      IgemmP p = IgemmP();
       p.nseg = op.nseg;
       for (int s = 0; s < op.nseg; ++s) {
         const lip_seg_t& g = op.seg[s];
@@ -94,10 +98,13 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
         q.IH = g.IH; q.IW = g.IW; q.C = g.C; q.KH = g.KH; q.KW = g.KW;
         q.stride = g.stride; q.pad_h = g.pad_h; q.pad_w = g.pad_w; q.mode = g.mode;
         q.Ktot = g.KH * g.KW * g.C;
+        q.dC = FastDiv((unsigned)(g.C > 0 ? g.C : 1)); q.dKW = FastDiv((unsigned)(g.KW > 0 ? g.KW : 1));
         if (!q.a || !q.b || q.Ktot <= 0 || q.stride <= 0) { set_error("IGEMM: bad segment %d", s); return LIP_ERR_ARG; }
         if ((q.C & 3) == 0 && ((((uintptr_t)q.a) & 15) || (q.a_ps & 3))) { set_error("IGEMM: segment %d activations not 16-byte aligned", s); return LIP_ERR_ARG; }
       }
       p.R = op.n_img * op.OH * op.OW; p.OHW = op.OH * op.OW; p.OW = op.OW; p.N = op.N;
+      if (op.OH <= 0 || op.OW <= 0) { set_error("IGEMM: bad geometry"); return LIP_ERR_ARG; }
+      p.dOHW = FastDiv((unsigned)p.OHW); p.dOW = FastDiv((unsigned)p.OW);
       p.out = resolve(c, op.out); p.out_ps = op.out.pstride;
       p.scale = resolve(c, op.scale);
       p.e0 = resolve(c, op.e0); p.e0_ps = op.e0.pstride;
@@ -116,14 +123,15 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
     }
     case LIP_OP_WGRAD: {
       const lip_seg_t& g = op.seg[0];
-      WgradP p;
-      memset(&p, 0, sizeof(p));
+      WgradP p = WgradP();
       p.a = resolve(c, g.a);
       p.IH = g.IH; p.IW = g.IW; p.C = g.C; p.KH = g.KH; p.KW = g.KW;
       p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
       p.g = resolve(c, g.b); p.g_ps = g.b.pstride;
       p.R = op.n_img * op.OH * op.OW; p.OHW = op.OH * op.OW; p.OW = op.OW; p.N = op.N;
       p.M = g.KH * g.KW * g.C;
+      if (op.OH <= 0 || op.OW <= 0) { set_error("WGRAD: bad geometry"); return LIP_ERR_ARG; }
+      p.dOHW = FastDiv((unsigned)p.OHW); p.dOW = FastDiv((unsigned)p.OW);
       p.y = resolve(c, op.out); p.y_ps = op.out.pstride;
       p.scale = resolve(c, op.scale);
       p.ksplit = op.ksplit > 0 ? op.ksplit : 1;
@@ -216,12 +224,28 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
   }
 }
 
+hipEvent_t next_event(lip_engine* e) {
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    e->ev_pool.push_back(ev);
+  }
+  return e->ev_pool[e->ev_used++];
+}
+
 int run_tape(const RunCtx& c, int which, bool skip_head) {
   const std::vector<lip_op_t>& t = c.e->tape[which];
   if (t.empty()) { set_error("tape %d is empty", which); return LIP_ERR_STATE; }
+  lip_engine* me = const_cast<lip_engine*>(c.e);
   for (size_t i = 0; i < t.size(); ++i) {
     if (skip_head && t[i].kind == LIP_OP_HEAD) continue;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (me->prof) {
+      e0 = next_event(me); e1 = next_event(me);
+      if (e0 && e1) { me->ev_kind.push_back(t[i].kind); (void)hipEventRecord(e0, c.st); }
+    }
     const int rc = run_op(c, t[i]);
+    if (me->prof && e0 && e1) (void)hipEventRecord(e1, c.st);
     if (rc != LIP_OK) {
       char buf[400];
       snprintf(buf, sizeof(buf), "%s", g_err);
@@ -256,6 +280,7 @@ int lip_engine_create(lip_engine_t** out, int64_t D, int32_t n_img, int32_t K) {
 }
 
 int lip_engine_destroy(lip_engine_t* e) {
+  if (e) for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   delete e;
   return LIP_OK;
 }
@@ -290,6 +315,30 @@ int lip_engine_primal(lip_engine_t* e, void* stream) {
   const int rc = run_tape(c, LIP_TAPE_PRIMAL, false);
   if (rc == LIP_OK) e->primal_done = true;
   return rc;
+}
+
+int lip_engine_profile(lip_engine_t* e, int32_t enable) {
+  if (!e) { set_error("lip_engine_profile: null engine"); return LIP_ERR_ARG; }
+  e->prof = enable != 0;
+  e->ev_used = 0;
+  e->ev_kind.clear();
+  return LIP_OK;
+}
+
+int lip_engine_profile_read(lip_engine_t* e, double* ms_by_kind, int64_t* launches_by_kind, int32_t nkinds) {
+  if (!e || !ms_by_kind || !launches_by_kind || nkinds <= 0) { set_error("lip_engine_profile_read: bad argument"); return LIP_ERR_ARG; }
+  for (int k = 0; k < nkinds; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+  for (size_t i = 0; i < e->ev_kind.size(); ++i) {
+    hipEvent_t a = e->ev_pool[2 * i], b = e->ev_pool[2 * i + 1];
+    RUN_CHECK(hipEventSynchronize(b), "hipEventSynchronize");
+    float ms = 0.f;
+    RUN_CHECK(hipEventElapsedTime(&ms, a, b), "hipEventElapsedTime");
+    const int k = e->ev_kind[i];
+    if (k >= 0 && k < nkinds) { ms_by_kind[k] += ms; launches_by_kind[k] += 1; }
+  }
+  e->ev_used = 0;
+  e->ev_kind.clear();
+  return LIP_OK;
 }
 
 int lip_debug_run_ops(lip_engine_t* e, int32_t which, int32_t first, int32_t count, const float* V, float* Y,

@@ -6,17 +6,38 @@
 
 namespace lip {
 
+// ---- division by a run-time constant without the ~40-instruction software divide --------------
+// q = (umulhi(n, m) + n) >> s  (round-up magic number; exact for 0 <= n < 2^31, d >= 1)
+struct FastDiv {
+  unsigned m, s, d;
+  FastDiv() : m(1), s(0), d(1) {}
+  explicit FastDiv(unsigned dd) : d(dd) {
+    s = 0;
+    while ((1ull << s) < dd) ++s;
+    m = (unsigned)((((1ull << s) - dd) << 32) / dd + 1);
+  }
+  __host__ __device__ __forceinline__ int div(int n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
+#else
+    return (int)((unsigned)n / d);
+#endif
+  }
+};
+
 // ---- resolved (device-pointer) parameter blocks handed to the kernels -------------------
 struct SegP {
   const float* a; long long a_ps;
   const float* b; long long b_ps;
   int IH, IW, C, KH, KW, stride, pad_h, pad_w, mode, Ktot;
+  FastDiv dC, dKW;
 };
 
 struct IgemmP {
   int nseg;
   SegP seg[3];
   int R, OHW, OW, N;
+  FastDiv dOHW, dOW;
   float* out; long long out_ps;
   const float* scale;
   const float* e0; long long e0_ps;
@@ -34,6 +55,7 @@ struct WgradP {
   int IH, IW, C, KH, KW, stride, pad_h, pad_w;
   const float* g; long long g_ps;       // cotangent [P][R][N]
   int R, OHW, OW, N, M;                 // M = KH*KW*C
+  FastDiv dOHW, dOW;
   float* y; long long y_ps;             // Y + param offset, element [m*N + co]
   const float* scale;                   // per-channel [N] or null
   int ksplit;

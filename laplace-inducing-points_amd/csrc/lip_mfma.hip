@@ -20,6 +20,7 @@
 //   C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // LDS images are k-major (As[k][m], Bs[k][n]) so every MFMA operand read is 32 consecutive
 // dwords per half-wave: conflict-free ds_read_b32.
+#include <stdlib.h>
 #include "lip_internal.h"
 
 namespace lip {
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
     const int m = (tid + j * NT) >> 2;
     const int r = r0 + m;
     if (r < R) {
-      const int i = r / prm.OHW, rem = r - i * prm.OHW;
-      vi[j] = i; voh[j] = rem / prm.OW; vow[j] = rem - voh[j] * prm.OW;
+      const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
+      vi[j] = i; voh[j] = prm.dOW.div(rem); vow[j] = rem - voh[j] * prm.OW;
     } else {
       vi[j] = -1; voh[j] = 0; vow[j] = 0;
     }
@@ -105,35 +106,54 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 
   float areg[AE], breg[BE];
 
+  // gathered input coordinate of output coordinate o under kernel tap k (lip_seg_t modes)
   auto gather_coord = [](const SegP& s, int o, int k, int pad, int lim, int& valid) -> int {
     int t;
     if (s.mode == 0) {
       t = o * s.stride + k - pad;
     } else {
       t = o + pad - k;
-      if (t < 0 || (t % s.stride) != 0) { valid = 0; return 0; }
-      t /= s.stride;
+      if (s.stride == 2) {
+        if (t & 1) valid = 0;
+        t >>= 1;                       // arithmetic shift keeps negatives negative
+      } else if (s.stride != 1) {
+        if (t < 0 || (t % s.stride) != 0) { valid = 0; return 0; }
+        t /= s.stride;
+      }
     }
     if (t < 0 || t >= lim) valid = 0;
     return t;
   };
 
-  auto load_tile = [&](const SegP& s, int k0) {
+  // K-tile cursor.  (kh, kw, c0) track the kernel tap of the tile with scalar adds only; they are
+  // meaningful when C % 16 == 0 (a BK = 16 tile never straddles a tap), the common case.
+  int seg = 0, k0 = 0, kh0 = 0, kw0 = 0, c0 = 0;
+
+  auto load_tile = [&](const SegP& s) {
     const float* abase = s.a + (long long)p * s.a_ps;
     if ((s.C & 3) == 0) {
+      const bool tap_uniform = (s.C & 15) == 0;
+      const bool one_tap = (s.KH * s.KW) == 1;
 #pragma unroll
       for (int j = 0; j < AQ; ++j) {
         const int kq = (tid + j * NT) & 3;
         const int kg = k0 + kq * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (vi[j] >= 0 && kg < s.Ktot) {
-          const int tap = kg / s.C, c = kg - tap * s.C;
-          const int kh = tap / s.KW, kw = tap - kh * s.KW;
+          int kh, kw, c;
+          if (tap_uniform) { kh = kh0; kw = kw0; c = c0 + kq * 4; }
+          else if (one_tap) { kh = 0; kw = 0; c = kg; }
+          else {
+            const int tap = s.dC.div(kg);
+            c = kg - tap * s.C;
+            kh = s.dKW.div(tap);
+            kw = tap - kh * s.KW;
+          }
           int valid = 1;
           const int ih = gather_coord(s, voh[j], kh, s.pad_h, s.IH, valid);
           const int iw = gather_coord(s, vow[j], kw, s.pad_w, s.IW, valid);
           if (valid)
-            v = *reinterpret_cast<const float4*>(abase + (((long long)vi[j] * s.IH + ih) * s.IW + iw) * s.C + c);
+            v = *reinterpret_cast<const float4*>(abase + (unsigned)(((vi[j] * s.IH + ih) * s.IW + iw) * s.C + c));
         }
         areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
       }
@@ -145,14 +165,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
         const int r = r0 + m, kg = k0 + k;
         float v = 0.f;
         if (r < R && kg < s.Ktot) {
-          const int i = r / prm.OHW, rem = r - i * prm.OHW;
-          const int oh = rem / prm.OW, ow = rem - oh * prm.OW;
-          const int tap = kg / s.C, c = kg - tap * s.C;
-          const int kh = tap / s.KW, kw = tap - kh * s.KW;
+          const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
+          const int oh = prm.dOW.div(rem), ow = rem - oh * prm.OW;
+          const int tap = s.dC.div(kg), c = kg - tap * s.C;
+          const int kh = s.dKW.div(tap), kw = tap - kh * s.KW;
           int valid = 1;
           const int ih = gather_coord(s, oh, kh, s.pad_h, s.IH, valid);
           const int iw = gather_coord(s, ow, kw, s.pad_w, s.IW, valid);
-          if (valid) v = abase[(((long long)i * s.IH + ih) * s.IW + iw) * s.C + c];
+          if (valid) v = abase[(unsigned)(((i * s.IH + ih) * s.IW + iw) * s.C + c)];
         }
         areg[j] = v;
       }
@@ -163,8 +183,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
       const int e = tid + j * NT;
       const int k = e / BN, nn = e - k * BN;
       const int kg = k0 + k, col = n0 + nn;
-      breg[j] = (kg < s.Ktot && col < N) ? bbase[(long long)kg * N + col] : 0.f;
+      breg[j] = (kg < s.Ktot && col < N) ? bbase[(unsigned)(kg * N + col)] : 0.f;
     }
+  };
+
+  // advance the cursor to the next K-tile; false when all segments are consumed
+  auto advance = [&]() -> bool {
+    const SegP& s = prm.seg[seg];
+    k0 += BK;
+    c0 += BK;
+    if (c0 >= s.C) { c0 -= s.C; if (++kw0 == s.KW) { kw0 = 0; ++kh0; } }
+    if (k0 >= s.Ktot) { ++seg; k0 = 0; c0 = 0; kh0 = 0; kw0 = 0; }
+    return seg < prm.nseg;
   };
 
   auto store_tile = [&](const SegP& s) {
@@ -191,16 +221,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
     }
   };
 
-  int seg = 0, k0 = 0;
-  load_tile(prm.seg[0], 0);
+  load_tile(prm.seg[0]);
   while (true) {
     __syncthreads();
     store_tile(prm.seg[seg]);
     __syncthreads();
-    k0 += BK;
-    if (k0 >= prm.seg[seg].Ktot) { ++seg; k0 = 0; }
-    const bool more = seg < prm.nseg;
-    if (more) load_tile(prm.seg[seg], k0);
+    const bool more = advance();
+    if (more) load_tile(prm.seg[seg]);
     mfma_sweep<WM, WN, TM, TN, LDA, LDB>(As, Bs, acc, wm, wn, lane);
     if (!more) break;
   }
@@ -223,7 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
       for (int reg = 0; reg < 16; ++reg) {
         const int r = r0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
         if (r < R && cv) {
-          const long long idx = (long long)r * N + col;
+          const unsigned idx = (unsigned)(r * N + col);
           float v = acc[tm][tn][reg] * sc + e0v;
           if (prm.e1) v += e1v * prm.xhat[idx];
           if (prm.res) v += prm.res[(long long)p * prm.res_ps + idx];
@@ -312,11 +339,11 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
         const int r = rk0 + k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mvalid && r < rend) {
-          const int i = r / prm.OHW, rem = r - i * prm.OHW;
-          const int oh = rem / prm.OW, ow = rem - oh * prm.OW;
+          const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
+          const int oh = prm.dOW.div(rem), ow = rem - oh * prm.OW;
           const int ih = oh * prm.stride + kh - prm.pad_h, iw = ow * prm.stride + kw - prm.pad_w;
           if (ih >= 0 && ih < prm.IH && iw >= 0 && iw < prm.IW)
-            v = *reinterpret_cast<const float4*>(prm.a + (((long long)i * prm.IH + ih) * prm.IW + iw) * prm.C + ci);
+            v = *reinterpret_cast<const float4*>(prm.a + (unsigned)(((i * prm.IH + ih) * prm.IW + iw) * prm.C + ci));
         }
         areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
       }
@@ -327,11 +354,11 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
         const int r = rk0 + k;
         float v = 0.f;
         if (mvalid && r < rend) {
-          const int i = r / prm.OHW, rem = r - i * prm.OHW;
-          const int oh = rem / prm.OW, ow = rem - oh * prm.OW;
+          const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
+          const int oh = prm.dOW.div(rem), ow = rem - oh * prm.OW;
           const int ih = oh * prm.stride + kh - prm.pad_h, iw = ow * prm.stride + kw - prm.pad_w;
           if (ih >= 0 && ih < prm.IH && iw >= 0 && iw < prm.IW)
-            v = prm.a[(((long long)i * prm.IH + ih) * prm.IW + iw) * prm.C + ci];
+            v = prm.a[(unsigned)(((i * prm.IH + ih) * prm.IW + iw) * prm.C + ci)];
         }
         areg[j] = v;
       }
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
       const int e = tid + j * NT;
       const int k = e / BN, nn = e - k * BN;
       const int r = rk0 + k, col = n0 + nn;
-      breg[j] = (r < rend && col < N) ? gbase[(long long)r * N + col] : 0.f;
+      breg[j] = (r < rend && col < N) ? gbase[(unsigned)(r * N + col)] : 0.f;
     }
   };
 
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
       for (int reg = 0; reg < 16; ++reg) {
         const int m = m0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
         if (m < M) {
-          float* dst = ybase + (long long)m * N + col;
+          float* dst = ybase + (unsigned)(m * N + col);
           const float v = acc[tm][tn][reg] * sc;
           if (prm.ksplit > 1) atomicAdd(dst, v);
           else *dst += v;
@@ -418,11 +445,18 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
   return hipGetLastError();
 }
 
+static int tile_override() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("LIP_TILE"); v = e ? atoi(e) : -1; }
+  return v;
+}
+
 hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   const bool small_m = p.R <= 64;
+  const bool big_m = p.R >= 4096 && tile_override() != 0;    // LIP_TILE=0: round-1 128-row tiles (A/B testing)
   if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);
-  if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st);
-  return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st);
+  if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 2>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st));
+  return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st));
 }
 
 template <int WM, int WN, int TM, int TN>

@@ -1,0 +1,59 @@
+"""Multi-GPU: the data sum of the GGN shards across ranks (one process per GPU, RCCL over xGMI).
+
+GGN v = sum_i J_i^T H_i J_i v is a sum of independent per-example terms (``src/ggn.py:136-144``): rank r
+holds theta, the probe block V and its slice Z_r of the data; the partial products are combined by ONE
+all-reduce (sum) of the (P, D) block per matvec.  W^T outputs disjoint row slices (all-gather of d
+floats); W consumes slices and its (P, D) outputs are all-reduced.  The reference has no multi-device
+code at all; this is new design, covered by world_size-2 gloo tests on the CPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced slices: the first n % world_size ranks get one extra example."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedDataSum:
+    """Wrap a rank-local block operator (the partial sum over this rank's examples) into the global one.
+
+    ``local(V) -> (P, D)`` must already carry the global recalibration N/M_total (so that the partial sums
+    simply add) but NOT the prior term alpha*V, which is added once after the reduction."""
+
+    def __init__(self, local: Callable[[torch.Tensor], torch.Tensor], alpha: float = 0.0,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.local, self.alpha, self.group = local, float(alpha), group
+
+    def __call__(self, V: torch.Tensor) -> torch.Tensor:
+        Y = self.local(V)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self.group)      # the one collective per matvec
+        if self.alpha != 0.0:
+            Y = Y.add_(V.reshape(Y.shape), alpha=self.alpha) if Y.is_cuda else Y + self.alpha * V.reshape(Y.shape)
+        return Y
+
+
+def sharded_ggn_vp(state, Z_local, model_type, alpha, n_total: int, full_set_size=None, group=None):
+    """Global (GGN + alpha I) block operator from this rank's data slice (HIP engine underneath)."""
+    import math
+    from .ggn import get_engine
+    eng = get_engine(state, Z_local, model_type)
+    N = full_set_size or n_total
+    scale = N / n_total * (math.exp(-float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0)
+    return ShardedDataSum(lambda V: eng.ggn_vp(V, scale, 0.0), alpha, group), eng
+
+
+def gather_rows(U_local: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather of the W^T slices (P, M_local, K) along the example axis (equal slice sizes)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return U_local
+    parts = [torch.empty_like(U_local) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, U_local.contiguous(), group=group)
+    return torch.cat(parts, dim=1)

@@ -439,6 +439,29 @@ def build_consts(cn: CompiledNet, params: Dict[str, Any], batch_stats: Dict[str,
     return out
 
 
+def tape_flops_per_probe(cn: CompiledNet):
+    """ALGORITHMIC FLOPs of one probe's tangent-forward + backward sweep, per op kind, from the tapes:
+    conv segment 2 R N Ktot; transposed (data-gradient) segment 2 x the MACs of the conv it differentiates
+    (the gather also visits stride-masked taps — those are not counted); WGRAD 2 R N M.
+    Totals 8 MACs_fwd per example minus the input layer's two absent terms."""
+    out = {}
+    for which in (1, 2):
+        for op in cn.tapes[which]:
+            R = op.n_img * op.OH * op.OW
+            if op.kind == nv.OP_IGEMM:
+                fl = 0
+                for i in range(op.nseg):
+                    sg = op.seg[i]
+                    if sg.mode == 0:
+                        fl += 2 * R * op.N * sg.KH * sg.KW * sg.C
+                    else:
+                        fl += 2 * op.n_img * sg.IH * sg.IW * sg.C * sg.KH * sg.KW * op.N
+                out[nv.OP_IGEMM] = out.get(nv.OP_IGEMM, 0) + fl
+            elif op.kind == nv.OP_WGRAD:
+                out[nv.OP_WGRAD] = out.get(nv.OP_WGRAD, 0) + 2 * R * op.N * op.M
+    return out
+
+
 class LinearizedNet:
     """The linearised-network operator bound to (network, theta_MAP, data slice Z) on one GPU.
 
@@ -512,6 +535,21 @@ class LinearizedNet:
     def probs(self) -> torch.Tensor:
         o = self.cn.prob_off
         return self.prim[o:o + self.n * self.K].reshape(self.n, self.K).clone()
+
+    # ------------------------------------------------------------------------------ measurement
+    def profile(self, enable: bool):
+        nv.check(self.lib.lip_engine_profile(self.h, int(enable)), "lip_engine_profile")
+
+    def profile_read(self):
+        """{op kind: (ms, launches)} accumulated since the last read (HIP events on the launch stream)."""
+        nk = 16
+        ms = (C.c_double * nk)()
+        cnt = (C.c_int64 * nk)()
+        nv.check(self.lib.lip_engine_profile_read(self.h, ms, cnt, nk), "lip_engine_profile_read")
+        return {k: (ms[k], cnt[k]) for k in range(nk) if cnt[k]}
+
+    def flops_per_probe(self):
+        return tape_flops_per_probe(self.cn)
 
     # ------------------------------------------------------------------------------ operators
     def ggn_vp(self, V: torch.Tensor, scale: float = 1.0, alpha: float = 0.0, out: Optional[torch.Tensor] = None):

@@ -76,17 +76,24 @@ def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Te
     c2 = torch.empty(P, k, device=dev, dtype=torch.float32)
     nrm2 = bdot(V0, V0)
     nv.check(lib.lip_scale_store(nv.ptr(V0), nv.ptr(nrm2), nv.ptr(Q), 0, P, k, N, st), "lip_scale_store")
+    alive = torch.ones(P, device=dev, dtype=torch.bool)
     for j in range(k):
         w = matvec(Q[:, j].contiguous()).contiguous()
         _chk(w)
+        wn2 = bdot(w, w)
         nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c1), P, j + 1, k, N, st), "lip_multi_dot")
         nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c1), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, st), "lip_multi_axpy_norm")
         nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c2), P, j + 1, k, N, st), "lip_multi_dot")
         nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c2), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, st), "lip_multi_axpy_norm")
-        diag[:, j] = c1[:, j] + c2[:, j]
+        # breakdown guard: once the Krylov space of a probe is exhausted (residual at rounding level)
+        # the remaining basis vectors are zero and the tridiagonal block decouples (diag 1, offdiag 0),
+        # which leaves f(T) e1 unchanged instead of producing 0/0.
+        diag[:, j] = torch.where(alive, c1[:, j] + c2[:, j], torch.ones_like(nrm2))
         if j + 1 < k:
-            off[:, j] = torch.sqrt(nrm2)
-            nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(nrm2), nv.ptr(Q), j + 1, P, k, N, st), "lip_scale_store")
+            alive = alive & (nrm2 > (1e-10 * wn2).clamp_min(1e-36))
+            off[:, j] = torch.where(alive, torch.sqrt(nrm2), torch.zeros_like(nrm2))
+            safe = torch.where(alive, nrm2, torch.full_like(nrm2, float("inf")))
+            nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(safe), nv.ptr(Q), j + 1, P, k, N, st), "lip_scale_store")
     return Q, diag, off
 
 

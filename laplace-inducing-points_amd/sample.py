@@ -1,0 +1,173 @@
+"""Posterior sampling — same call surface as the reference's ``src/sample.py``.
+
+``sample`` (``:148``), ``inv_matsqrt_vp`` (``:55``), ``inv_matsqrt_dense`` (``:16``), ``sample_dense``
+(``:159``), ``sample_both`` (``:168``), plus ``sample_lanczos`` (D-space Lanczos on GGN + alpha I, the
+variant BASELINE.json's north star names).
+
+A = alpha I + beta W W^T (W built at N/M = 1, beta = N/M applied here: ``:64,109-111``):
+  A^(-1/2) v = W (W^T W)^+ f(alpha I_d + beta W^T W) W^T v + alpha^(-1/2) (v - W (W^T W)^+ W^T v),
+f(x) = x^(-1/2) evaluated by a min(2M, d)-step Lanczos in the small d = M K space (``:113-128``).
+W is linear, so both terms share ONE W^T sweep and ONE W sweep per sample block (the reference does
+two of each per sample, sequentially: ``:78-85,130-139,155``).
+
+Decisions on the reference's defects (documented in DESIGN.md):
+  * ``clip_min``: the reference evaluates f(max(lambda, 1)) through its monkey-patched eigh
+    (``src/matfree_monkeypatch.py:19``); default here is the mathematics (``None``); pass
+    ``clip_min=REFERENCE_CLIP_MIN`` for the reference's behaviour.
+  * (W^T W) is singular for the classifier (rank K-1 per example, §4.1-5) and whenever d > D; the
+    reference calls ``solve`` on it.  Here the Moore-Penrose pseudo-inverse is used (identical when
+    W^T W is invertible).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import krylov
+from .ggn import BlockOperator, build_WTW, compute_ggn_vp, compute_W_vps
+from .utils import flatten_nn_params
+
+REFERENCE_CLIP_MIN = 1.0
+
+
+def _seed(key) -> int:
+    if key is None:
+        return 0
+    if torch.is_tensor(key):
+        return int(key.reshape(-1)[0].item())
+    return int(key)
+
+
+def _pinv_sym(G: torch.Tensor, rtol: float = 1e-6) -> torch.Tensor:
+    """Pseudo-inverse of the symmetric PSD Gram matrix (float64 on device; d <= ~1000)."""
+    ev, U = torch.linalg.eigh(G.double())
+    keep = ev > rtol * ev.max().clamp_min(1e-300)
+    inv = torch.where(keep, 1.0 / ev.clamp_min(1e-300), torch.zeros_like(ev))
+    return ((U * inv) @ U.T)
+
+
+class _SamplerParts:
+    """Everything ``inv_matsqrt_vp`` precomputes once per (state, Z, alpha)."""
+
+    def __init__(self, state, Z, D, alpha, model_type, full_set_size, clip_min, method):
+        self.Wfun, self.WTfun = compute_W_vps(state, Z, model_type, full_set_size=None)   # :64
+        eng = self.Wfun.engine
+        self.eng, self.alpha = eng, float(alpha)
+        M = Z.shape[0]
+        N = full_set_size or M
+        self.beta = N / M
+        self.inner = self.WTfun.out_shape
+        self.d = math.prod(self.inner)
+        self.WTW = build_WTW(self.Wfun, self.WTfun, self.inner, self.d, dtype=torch.float32, block=2)   # :77
+        self.G_pinv = _pinv_sym(self.WTW).float().contiguous()
+        self.A_d = (self.alpha * torch.eye(self.d, device=eng.device, dtype=torch.float32) + self.beta * self.WTW).contiguous()
+        self.depth = min(2 * M, self.d)                                                     # :114
+        self.clip_min, self.method = clip_min, method
+        f = lambda x: 1.0 / torch.sqrt(x)
+        if method == "lanczos":
+            self.funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(f, clip_min), self.depth)   # :113-115
+        elif method == "eigh":
+            self.fA = krylov.dense_funm_sym_eigh(f, clip_min)(self.A_d.double()).float().contiguous()
+        else:
+            raise ValueError("method must be 'lanczos' or 'eigh'")
+
+    def f_small(self, U: torch.Tensor) -> torch.Tensor:
+        """f(alpha I + beta W^T W) applied to the rows of U (S, d)."""
+        if self.method == "eigh":
+            return U @ self.fA
+        return self.funm(lambda X: X @ self.A_d, U.contiguous())                           # :117-128
+
+    def apply(self, V: torch.Tensor) -> torch.Tensor:
+        """rows of V (S, D) -> A^(-1/2) V"""
+        S = V.shape[0]
+        U = self.WTfun.rows(V).reshape(S, self.d)                                          # W^T v
+        x1 = self.f_small(U) @ self.G_pinv                                                 # :130-138
+        x2 = U @ self.G_pinv                                                               # :78-84
+        a = 1.0 / math.sqrt(self.alpha)
+        out = self.Wfun.rows((x1 - a * x2).reshape((S,) + self.inner))                     # one W sweep
+        return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
+
+
+def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None, num_proj_steps=1,
+                   clip_min: Optional[float] = None, method: str = "lanczos"):
+    """``src/sample.py:55-145``.  Returns a block operator v -> A^(-1/2) v on (D,) or (S, D).
+    (``key`` / ``num_proj_steps`` select the reference's alternating-projection branch, which it
+    disables itself — ``:150`` forces ``key=None`` because the branch returns NaN)"""
+    parts = _SamplerParts(state, Z, D, alpha, model_type, full_set_size, clip_min, method)
+    eng = parts.eng
+    op = BlockOperator(lambda V: parts.apply(V.to(device=eng.device, dtype=torch.float32).contiguous()),
+                       (eng.D,), (eng.D,), eng, "inv_matsqrt_vp")
+    op.parts = parts
+    return op
+
+
+def sample(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None, num_proj_steps=10,
+           clip_min: Optional[float] = None, method: str = "lanczos", block: int = 256):
+    """``src/sample.py:148-156``: ``num_samples`` zero-mean draws A^(-1/2) eps, eps ~ N(0, I) -> (S, D).
+    (theta_MAP is *not* added, as in the reference: ``:153-154``.)  eps comes from the in-kernel
+    Philox generator seeded by ``key``; bit parity with JAX's threefry is not attempted."""
+    fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, key=None,
+                         num_proj_steps=num_proj_steps, clip_min=clip_min, method=method)
+    eng = fun.engine
+    outs = []
+    for s in range(0, num_samples, block):
+        e = min(num_samples, s + block)
+        Eps = krylov.fill_normal(e - s, eng.D, _seed(key) * 1000003 + s, eng.device)
+        outs.append(fun.rows(Eps))
+    return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+
+def sample_lanczos(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None, num_matvecs=36,
+                   clip_min: Optional[float] = None):
+    """D-space variant: (GGN + alpha I)^(-1/2) eps by ``num_matvecs``-step Lanczos with full
+    re-orthogonalisation on the matrix-free GGN-vector product (the Krylov loop of BASELINE.json's north
+    star; the reference only runs its Lanczos in the small d-space)."""
+    vp = compute_ggn_vp(state, Z, model_type, full_set_size=full_set_size)
+    eng = vp.engine
+    M = Z.shape[0]
+    N = full_set_size or M
+    scale = N / M * (math.exp(-float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0)
+    matvec = lambda V: eng.ggn_vp(V, scale, float(alpha))
+    funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(lambda x: 1.0 / torch.sqrt(x), clip_min), num_matvecs)
+    Eps = krylov.fill_normal(num_samples, eng.D, _seed(key) * 1000003, eng.device)
+    return funm(matvec, Eps)
+
+
+def inv_matsqrt_dense(state, Z, D, alpha, model_type, full_set_size=None):
+    """``src/sample.py:16-52`` (debug twin): materialise W (D, d) and use eigh."""
+    Wfun, WTfun = compute_W_vps(state, Z, model_type, full_set_size=None)
+    eng = Wfun.engine
+    Dn = eng.D
+    M = Z.shape[0]
+    N = full_set_size or M
+    beta = N / M
+    d = math.prod(WTfun.out_shape)
+    E = torch.eye(d, device=eng.device, dtype=torch.float32).reshape((d,) + WTfun.out_shape)
+    W = Wfun.rows(E).T.double()                                   # (D, d)
+    composite = W.T @ W
+    inv_composite = _pinv_sym(composite)
+    I_D = torch.eye(Dn, device=eng.device, dtype=torch.float64)
+    nullproj = I_D - W @ inv_composite @ W.T
+    evals, evecs = torch.linalg.eigh(alpha * torch.eye(d, device=eng.device, dtype=torch.float64) + beta * composite)
+    inv_sqrt_term = (evecs * (1.0 / torch.sqrt(torch.clamp(evals, min=1e-300)))) @ evecs.T
+    return (nullproj / math.sqrt(alpha) + W @ inv_composite @ inv_sqrt_term @ W.T).float()
+
+
+def sample_dense(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None):
+    """``src/sample.py:159-165`` (adds theta_MAP, unlike ``sample``)."""
+    A = inv_matsqrt_dense(state, Z, D, alpha, model_type, full_set_size=full_set_size)
+    flat_params, _ = flatten_nn_params(state.params)
+    Eps = krylov.fill_normal(num_samples, A.shape[0], _seed(key) * 1000003, A.device)
+    return Eps @ A.T + flat_params.to(A.device, torch.float32)
+
+
+def sample_both(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None,
+                clip_min: Optional[float] = None, method: str = "lanczos"):
+    """``src/sample.py:168-178``: the matrix-free and the dense sampler on the same noise."""
+    fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, clip_min=clip_min, method=method)
+    Eps = krylov.fill_normal(num_samples, fun.engine.D, _seed(key) * 1000003, fun.engine.device)
+    samples = fun.rows(Eps)
+    A = inv_matsqrt_dense(state, Z, D, alpha, model_type, full_set_size=full_set_size)
+    return samples, Eps @ A.T

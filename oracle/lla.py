@@ -62,13 +62,14 @@ def predict_lla_dense(map_state, Xnew, Z, model_type, alpha, full_set_size=None)
     return MultivariateNormalFullCovariance(loc=f_mean, covariance_matrix=f_cov)
 
 
-def predict_lla_scalable(map_state, Xnew, Z, model_type, alpha, key=None, full_set_size=None, num_samples=1):
+def predict_lla_scalable(map_state, Xnew, Z, model_type, alpha, key=None, full_set_size=None, num_samples=1,
+                         **sample_kw):
     """``src/lla.py:133-156``: f(x; theta) + J(x) w_s with w_s ~ sample(...)  -> (S, B, C)."""
     flat_params, unravel_fn = flatten_nn_params(map_state.params)
     D = flat_params.shape[0]
     key = key if key is not None else 123
     w_samples = sample(map_state, Z, D, alpha=alpha, key=key, model_type=model_type,
-                       num_samples=num_samples, full_set_size=full_set_size)
+                       num_samples=num_samples, full_set_size=full_set_size, **sample_kw)
     model_fun = _flat_apply(map_state, unravel_fn, model_type)
     fmu = model_fun(flat_params, Xnew)
     fz = lambda p: model_fun(p, Xnew)

@@ -43,6 +43,11 @@ def tridiag_sym(num_matvecs: int, reortho: str = "full"):
             diag[j] = a
             if j + 1 < k:
                 beta = torch.linalg.vector_norm(w)
+                if float(beta) <= 1e-13 * max(float(abs(a)), 1e-300):
+                    # Krylov space exhausted (matfree has no guard here and would divide by ~0):
+                    # decouple the remaining block (diag 1, offdiag 0) so that f(T) e1 is unchanged.
+                    diag[j + 1:] = 1.0
+                    break
                 off[j] = beta
                 q_prev = q
                 q = w / beta

@@ -18,6 +18,21 @@ from .ggn import build_WTW, compute_W_vps
 from .matfree import dense_funm_sym_eigh, funm_lanczos_sym, tridiag_sym
 
 REFERENCE_CLIP_MIN = 1.0
+PRODUCT_GRAM_RTOL = 1e-6
+
+
+def _gram_solver(WTW, gram_rtol):
+    """``gram_rtol=None``: the reference's literal ``solve(W^T W, .)`` (``src/sample.py:81-84,135-138``) —
+    ill-posed whenever the Gram is (numerically) singular: always for the classifier and for
+    neighbouring regression points (cond ~1e17 on the sine fixture).  ``gram_rtol=r``: the truncated
+    Moore-Penrose pseudo-inverse the product path uses (eigenvalues <= r * max dropped); identical to
+    ``solve`` when the Gram is well conditioned."""
+    if gram_rtol is None:
+        return lambda u: torch.linalg.solve(WTW, u)
+    ev, U = torch.linalg.eigh(WTW)
+    inv = torch.where(ev > gram_rtol * ev.max(), 1.0 / ev.clamp_min(1e-300), torch.zeros_like(ev))
+    Gp = (U * inv) @ U.T
+    return lambda u: Gp @ u
 
 
 def _normal(key, shape, dtype):
@@ -48,7 +63,7 @@ def inv_matsqrt_dense(state, Z, D, alpha, model_type, full_set_size=None):
 
 
 def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None, num_proj_steps=1,
-                   clip_min=REFERENCE_CLIP_MIN):
+                   clip_min=REFERENCE_CLIP_MIN, gram_rtol=None):
     """``src/sample.py:55-145``: v -> W (W^T W)^-1 f(alpha I + beta W^T W) W^T v
     + alpha^(-1/2) (v - W (W^T W)^-1 W^T v), f by 2M-step Lanczos in d-space."""
     Wfun, WTfun = compute_W_vps(state, Z, model_type, full_set_size=None)       # :64
@@ -58,10 +73,11 @@ def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None,
     inner_shape = tuple(dummy.shape)
     d = dummy.numel()
     WTW = build_WTW(Wfun, WTfun, inner_shape, d, dtype=dtype, block=2)           # :77
+    gsolve = _gram_solver(WTW, gram_rtol)
 
     def nullproj_vp(v):                                                          # :78-85
         u = WTfun(v).reshape(-1)
-        x = torch.linalg.solve(WTW, u)
+        x = gsolve(u)
         return v - Wfun(x.reshape(inner_shape))
 
     nullproj_term = lambda v: nullproj_vp(v) / alpha ** 0.5                      # :107
@@ -78,19 +94,19 @@ def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None,
 
     def outer_fun(v):                                                            # :130-139
         u = invmatsqrt_term(WTfun(v)).reshape(-1)
-        x = torch.linalg.solve(WTW, u)
+        x = gsolve(u)
         return Wfun(x.reshape(inner_shape))
 
     return lambda v: outer_fun(v) + nullproj_term(v)                             # :141-143
 
 
 def sample(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None, num_proj_steps=10,
-           clip_min=REFERENCE_CLIP_MIN):
+           clip_min=REFERENCE_CLIP_MIN, gram_rtol=None):
     """``src/sample.py:148-156``: zero-mean samples A^(-1/2) eps, eps ~ N(0, I) (S, D)."""
     flat_params, _ = flatten_nn_params(state.params)
     Eps = _normal(key, (num_samples, D), flat_params.dtype)
     fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, key=None,
-                         num_proj_steps=num_proj_steps, clip_min=clip_min)
+                         num_proj_steps=num_proj_steps, clip_min=clip_min, gram_rtol=gram_rtol)
     return torch.stack([fun(e) for e in Eps])
 
 

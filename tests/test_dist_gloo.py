@@ -1,0 +1,71 @@
+"""world_size-2 gloo test (CPU) of the data-sum sharding: the all-reduced partial GGN products of two
+ranks equal the single-process product over the whole data set."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import lip_amd  # noqa: F401
+    from lip_amd.dist import ShardedDataSum, gather_rows, shard_bounds
+    from lip_amd.toymodels import SimpleClassifier, create_state
+    from oracle.ggn import compute_ggn_vp, compute_W_vps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    net = SimpleClassifier(6, 2, 3)
+    st = create_state(net, 5, dtype=torch.float64)
+    g = torch.Generator().manual_seed(0)
+    Z = torch.randn(7, 2, dtype=torch.float64, generator=g)          # ragged split: 4 + 3
+    V = torch.randn(3, 81, dtype=torch.float64, generator=g)          # D = 2*6+6 + 6*6+6 + 6*3+3
+    lo, hi = shard_bounds(7, world, rank)
+    alpha, N = 0.3, 21
+    # local partial sum carries the GLOBAL recalibration N / n_total: oracle's factor is N/M_local -> rescale
+    vp_loc = compute_ggn_vp(st, Z[lo:hi], "classifier", full_set_size=N)
+    fix = (hi - lo) / 7.0
+    op = ShardedDataSum(lambda B: torch.stack([vp_loc(v) for v in B]) * fix, alpha)
+    Y = op(V)
+    vp_full = compute_ggn_vp(st, Z, "classifier", full_set_size=N)
+    ref = torch.stack([vp_full(v) + alpha * v for v in V])
+    err = (Y - ref).abs().max().item()
+    # W^T slices gather to the full (M, K) block when the slices are equal-sized
+    Z8 = torch.randn(8, 2, dtype=torch.float64, generator=g)
+    lo8, hi8 = shard_bounds(8, world, rank)
+    _, WT_loc = compute_W_vps(st, Z8[lo8:hi8], "classifier")
+    _, WT_full = compute_W_vps(st, Z8, "classifier")
+    U = gather_rows(WT_loc(V[0])[None])[0]
+    err2 = (U - WT_full(V[0])).abs().max().item()
+    ret[rank] = (err, err2)
+    dist.destroy_process_group()
+
+
+def test_sharded_data_sum_world2():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        err, err2 = ret[r]
+        assert err < 1e-10, f"rank {r}: sharded GGN-vp differs by {err}"
+        assert err2 < 1e-12, f"rank {r}: gathered W^T differs by {err2}"
+
+
+def test_shard_bounds_cover():
+    from lip_amd.dist import shard_bounds
+    for n in (1, 7, 50, 256):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,69 @@
+"""CPU: the NetSpec -> op-tape compiler + the op semantics of include/lip.h reproduce the oracle
+(float64, 1e-12) for every model family, including BN / residual / stride-2 projection / mean-pool."""
+import math
+
+import pytest
+import torch
+
+from lip_amd import _native as nv
+from lip_amd.engine import build_consts, compile_net
+from lip_amd.scalemodels import LargeClassifier, ResNet1M
+from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
+from lip_amd.utils import flatten_nn_params
+from oracle.ggn import compute_ggn_vp, compute_W_vps
+from tape_emulator import TapeMachine
+
+F64 = torch.float64
+G = torch.Generator().manual_seed(0)
+CASES = {
+    "regressor": (SimpleRegressor(8, 4), torch.randn(5, 1, dtype=F64, generator=G), "regressor", 20),
+    "classifier": (SimpleClassifier(16, 2, 2), torch.randn(6, 2, dtype=F64, generator=G), "classifier", None),
+    "large": (LargeClassifier((6, 6, 1), [24, 16], 2, 5), torch.rand(4, 6, 6, 1, dtype=F64, generator=G), "classifier", 11),
+    "resnet": (ResNet1M(4, input_shape=(8, 8, 3), widths=(4, 8, 12), blocks_per_stage=2),
+               torch.rand(3, 8, 8, 3, dtype=F64, generator=G), "classifier", None),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_tapes_reproduce_oracle(name):
+    net, Z, model_type, full = CASES[name]
+    st = create_state(net, 3, dtype=F64, logvar=-0.3)
+    n, P = Z.shape[0], 2
+    cn = compile_net(net, n, st.params)
+    flat, _ = flatten_nn_params(st.params)
+    tm = TapeMachine(cn, flat, build_consts(cn, st.params, st.batch_stats, "cpu", F64), Z, chunk=P)
+    tm.primal()
+    f_or = st.apply_fn({"params": st.params["params"]}, Z, return_logvar=False)
+    o = cn.a_off[net.out]
+    assert torch.allclose(tm.prim[o:o + n * cn.K].reshape(n, cn.K), f_or, atol=1e-12)
+    V = torch.randn(P, cn.D, dtype=F64, generator=torch.Generator().manual_seed(1))
+    N = full or n
+    lv = st.params["logvar"]["logvar"].item() if model_type == "regressor" else 0.0
+    Y = tm.ggn_vp(V, N / n * math.exp(-lv), 0.37)
+    vp = compute_ggn_vp(st, Z, model_type, full_set_size=full)
+    Yo = torch.stack([vp(v) + 0.37 * v for v in V])
+    assert torch.allclose(Y, Yo, rtol=1e-10, atol=1e-12 * Yo.abs().max().item())
+    Wf, WTf = compute_W_vps(st, Z, model_type, full_set_size=full)
+    c = math.sqrt(N / n) * math.exp(-0.5 * lv)
+    U = tm.jvp(V, nv.HEAD_LT, c)
+    Uo = torch.stack([WTf(v).reshape(n, -1) for v in V])
+    assert torch.allclose(U, Uo, rtol=1e-10, atol=1e-12)
+    Ur = torch.randn(P, n, cn.K, dtype=F64, generator=torch.Generator().manual_seed(2))
+    Yw = tm.vjp(Ur, nv.HEAD_L, c)
+    Ywo = torch.stack([Wf(u if model_type == "classifier" else u.reshape(n)) for u in Ur])
+    assert torch.allclose(Yw, Ywo, rtol=1e-10, atol=1e-12 * Ywo.abs().max().item())
+
+
+def test_resnet1m_layout_matches_survey():
+    """D and MACs/example of the headline workload (1 084 586 and 162 366 720)."""
+    net = ResNet1M(10)
+    st = create_state(net, 0)
+    flat, _ = flatten_nn_params(st.params)
+    assert flat.numel() == 1_084_586 and net.macs_per_example() == 162_366_720
+    cn = compile_net(net, 50, st.params)
+    assert cn.D == 1_084_586 and cn.K == 10
+    # the tapes' FLOP count is the 8 * MACs model of SURVEY §8d minus the input layer's two absent terms
+    from lip_amd.engine import tape_flops_per_probe
+    fl = sum(tape_flops_per_probe(cn).values())
+    first = 32 * 32 * 27 * 32
+    assert fl == 50 * (8 * 162_366_720 - 4 * first)
