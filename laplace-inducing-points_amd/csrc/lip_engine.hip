@@ -99,6 +99,8 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
         q.stride = g.stride; q.pad_h = g.pad_h; q.pad_w = g.pad_w; q.mode = g.mode;
         q.Ktot = g.KH * g.KW * g.C;
         q.dC = FastDiv((unsigned)(g.C > 0 ? g.C : 1)); q.dKW = FastDiv((unsigned)(g.KW > 0 ? g.KW : 1));
+        if (g.mode == 0) { q.mul = g.stride; q.sgn = 1; q.off_h = -g.pad_h; q.off_w = -g.pad_w; q.mask = 0; q.sh = 0; }
+        else { q.mul = 1; q.sgn = -1; q.off_h = g.pad_h; q.off_w = g.pad_w; q.mask = g.stride - 1; q.sh = (g.stride == 2) ? 1 : 0; }
         if (!q.a || !q.b || q.Ktot <= 0 || q.stride <= 0) { set_error("IGEMM: bad segment %d", s); return LIP_ERR_ARG; }
         if ((q.C & 3) == 0 && ((((uintptr_t)q.a) & 15) || (q.a_ps & 3))) { set_error("IGEMM: segment %d activations not 16-byte aligned", s); return LIP_ERR_ARG; }
       }

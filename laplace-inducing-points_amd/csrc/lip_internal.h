@@ -31,6 +31,9 @@ struct SegP {
   const float* b; long long b_ps;
   int IH, IW, C, KH, KW, stride, pad_h, pad_w, mode, Ktot;
   FastDiv dC, dKW;
+  // branch-free gather coordinate (fast kernel; stride in {1, 2}):
+  //   t0 = o * mul + sgn * k + off ;  valid iff (t0 & mask) == 0 && 0 <= (t0 >> sh) < lim
+  int mul, sgn, off_h, off_w, mask, sh;
 };
 
 struct IgemmP {

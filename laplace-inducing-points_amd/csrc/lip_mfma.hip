@@ -60,6 +60,63 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ As, const f
   }
 }
 
+// Fused epilogue shared by the generic and the fast implicit-GEMM kernels.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[TM][TN], float* redbuf, int p, int r0,
+                                               int n0, int wm, int wn, int lane, int tid) {
+  using T = Tile<WM, WN, TM, TN>;
+  constexpr int NT = T::NT, BN = T::BN;
+  const int N = prm.N, R = prm.R;
+  // ---- fused epilogue --------------------------------------------------------------------
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int cl = (wn * TN + tn) * 32 + l31;
+    const int col = n0 + cl;
+    const bool cv = col < N;
+    const float sc = (prm.scale && cv) ? prm.scale[col] : 1.f;
+    const float e0v = (prm.e0 && cv) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
+    const float e1v = (prm.e1 && cv) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = r0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (r < R && cv) {
+          const unsigned idx = (unsigned)(r * N + col);
+          float v = acc[tm][tn][reg] * sc + e0v;
+          if (prm.e1) v += e1v * prm.xhat[idx];
+          if (prm.res) v += prm.res[(long long)p * prm.res_ps + idx];
+          if (prm.dphi) v *= prm.dphi[idx];
+          prm.out[(long long)p * prm.out_ps + idx] = v;
+          s0 += v;
+          if (prm.red1) s1 += v * prm.xhat2[idx];
+        }
+      }
+    }
+    if (do_red) {
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (lh == 0) {
+        atomicAdd(&redbuf[cl], s0);
+        atomicAdd(&redbuf[BN + cl], s1);
+      }
+    }
+  }
+  if (do_red) {
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      const int col = n0 + c;
+      if (col < N) {
+        if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + col, redbuf[c]);
+        if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + col, redbuf[BN + c]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // implicit GEMM
 // ------------------------------------------------------------------------------------------
@@ -232,54 +289,150 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
     if (!more) break;
   }
 
-  // ---- fused epilogue --------------------------------------------------------------------
-  const int l31 = lane & 31, lh = lane >> 5;
-  const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
+  igemm_epilogue<WM, WN, TM, TN>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
+}
+
+// ------------------------------------------------------------------------------------------
+// implicit GEMM, specialised straight-line variant for the hot configuration:
+//   every segment has C % 16 == 0 (a BK = 16 K-tile never straddles a kernel tap), stride in {1, 2},
+//   16-byte aligned activations.  Per kernel tap the gathered row offsets / validity are computed
+//   once (branch-free, host-precomputed segment scalars) and reused for the C/16 K-tiles of the tap;
+//   B and LDS offsets are loop invariant.  ~8 non-MFMA instructions per MFMA instead of ~30.
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
+  using T = Tile<WM, WN, TM, TN>;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
+  constexpr int LDA = BM + 2, LDB = BN;
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+  __shared__ float redbuf[2 * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int N = prm.N, R = prm.R;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int p = blockIdx.y;
+  const int r0 = tile_m * BM, n0 = tile_n * BN;
+
+  for (int i = tid; i < 2 * BN; i += NT) redbuf[i] = 0.f;
+
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int cl = (wn * TN + tn) * 32 + l31;
-    const int col = n0 + cl;
-    const bool cv = col < N;
-    const float sc = (prm.scale && cv) ? prm.scale[col] : 1.f;
-    const float e0v = (prm.e0 && cv) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
-    const float e1v = (prm.e1 && cv) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
-    float s0 = 0.f, s1 = 0.f;
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int r = r0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (r < R && cv) {
-          const unsigned idx = (unsigned)(r * N + col);
-          float v = acc[tm][tn][reg] * sc + e0v;
-          if (prm.e1) v += e1v * prm.xhat[idx];
-          if (prm.res) v += prm.res[(long long)p * prm.res_ps + idx];
-          if (prm.dphi) v *= prm.dphi[idx];
-          prm.out[(long long)p * prm.out_ps + idx] = v;
-          s0 += v;
-          if (prm.red1) s1 += v * prm.xhat2[idx];
-        }
-      }
-    }
-    if (do_red) {
-      s0 += __shfl_xor(s0, 32, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      if (lh == 0) {
-        atomicAdd(&redbuf[cl], s0);
-        atomicAdd(&redbuf[BN + cl], s1);
-      }
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  // thread -> (row m_j, k-quad kq): quad q = tid + j*NT, m_j = q >> 2, kq = tid & 3 (NT % 4 == 0)
+  const int kq4 = (tid & 3) * 4;
+  int vi[AQ], voh[AQ], vow[AQ];
+#pragma unroll
+  for (int j = 0; j < AQ; ++j) {
+    const int r = r0 + ((tid + j * NT) >> 2);
+    if (r < R) {
+      const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
+      vi[j] = i; voh[j] = prm.dOW.div(rem); vow[j] = rem - voh[j] * prm.OW;
+    } else {
+      vi[j] = -1; voh[j] = 0; vow[j] = 0;
     }
   }
-  if (do_red) {
+  // loop-invariant B element offsets: e = tid + j*NT -> (k = e / BN, nn = e % BN)
+  unsigned bidx[BE];
+  bool bok[BE];
+#pragma unroll
+  for (int j = 0; j < BE; ++j) {
+    const int e = tid + j * NT;
+    const int k = e / BN, nn = e - k * BN;
+    bok[j] = (n0 + nn) < N;
+    bidx[j] = (unsigned)(k * N + n0 + nn);
+  }
+
+  float areg[AE], breg[BE];
+  int rowoff[AQ];
+  bool rowok[AQ];
+
+  // segment scalars + K cursor
+  int seg = 0, kh = 0, kw = 0, c0 = 0;
+  const float* abase = nullptr;
+  const float* bbase = nullptr;
+  int sIH = 0, sIW = 0, sC = 0, sKH = 0, sKW = 0, smul = 0, ssgn = 0, soffh = 0, soffw = 0, smask = 0, ssh = 0;
+
+  auto begin_segment = [&]() {
+    const SegP& s = prm.seg[seg];
+    abase = s.a + (long long)p * s.a_ps;
+    bbase = s.b + (long long)p * s.b_ps;
+    sIH = s.IH; sIW = s.IW; sC = s.C; sKH = s.KH; sKW = s.KW;
+    smul = s.mul; ssgn = s.sgn; soffh = s.off_h; soffw = s.off_w; smask = s.mask; ssh = s.sh;
+    kh = 0; kw = 0; c0 = 0;
+  };
+  auto set_tap = [&]() {
+    const int th = ssgn * kh + soffh, tw = ssgn * kw + soffw;      // scalar
+#pragma unroll
+    for (int j = 0; j < AQ; ++j) {
+      const int t0h = voh[j] * smul + th, t0w = vow[j] * smul + tw;
+      const int ih = t0h >> ssh, iw = t0w >> ssh;
+      rowok[j] = (vi[j] >= 0) && (((t0h | t0w) & smask) == 0) && ((unsigned)ih < (unsigned)sIH) &&
+                 ((unsigned)iw < (unsigned)sIW);
+      rowoff[j] = ((vi[j] * sIH + ih) * sIW + iw) * sC + kq4;
+    }
+  };
+  auto load_tile = [&]() {
+    const float* ap = abase + c0;
+#pragma unroll
+    for (int j = 0; j < AQ; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rowok[j]) v = *reinterpret_cast<const float4*>(ap + (unsigned)rowoff[j]);
+      areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < BE; ++j) breg[j] = bok[j] ? bbase[bidx[j]] : 0.f;
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < AQ; ++j) {
+      const int m = (tid + j * NT) >> 2;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) As[(kq4 + t) * LDA + m] = areg[4 * j + t];
+    }
+#pragma unroll
+    for (int j = 0; j < BE; ++j) {
+      const int e = tid + j * NT;
+      const int k = e / BN, nn = e - k * BN;
+      Bs[k * LDB + nn] = breg[j];
+    }
+  };
+  // move to the next K-tile; false when all segments are consumed
+  auto advance = [&]() -> bool {
+    c0 += BK;
+    bbase += BK * N;
+    if (c0 == sC) {
+      c0 = 0;
+      if (++kw == sKW) { kw = 0; ++kh; }
+      if (kh == sKH) {
+        if (++seg == prm.nseg) return false;
+        begin_segment();
+      }
+      set_tap();
+    }
+    return true;
+  };
+
+  begin_segment();
+  set_tap();
+  load_tile();
+  while (true) {
     __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-      const int col = n0 + c;
-      if (col < N) {
-        if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + col, redbuf[c]);
-        if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + col, redbuf[BN + c]);
-      }
-    }
+    store_tile();
+    __syncthreads();
+    const bool more = advance();
+    if (more) load_tile();
+    mfma_sweep<WM, WN, TM, TN, LDA, LDB>(As, Bs, acc, wm, wn, lane);
+    if (!more) break;
   }
+  igemm_epilogue<WM, WN, TM, TN>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -436,12 +589,25 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
 // ------------------------------------------------------------------------------------------
 // launchers: pick the tile shape from the problem shape
 // ------------------------------------------------------------------------------------------
+static bool igemm_fast_ok(const IgemmP& p) {
+  for (int s = 0; s < p.nseg; ++s) {
+    const SegP& q = p.seg[s];
+    if ((q.C & 15) != 0 || (q.stride != 1 && q.stride != 2)) return false;
+    if ((((uintptr_t)q.a) & 15) || (q.a_ps & 3)) return false;
+  }
+  return true;
+}
+
 template <int WM, int WN, int TM, int TN>
 static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
   using T = Tile<WM, WN, TM, TN>;
   const long long tiles = (long long)((p.R + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
   dim3 grid((unsigned)tiles, (unsigned)P, 1);
-  hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
+  static const bool force_generic = getenv("LIP_GENERIC") != nullptr;     // A/B switch
+  if (!force_generic && igemm_fast_ok(p))
+    hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
   return hipGetLastError();
 }
 
@@ -453,7 +619,7 @@ static int tile_override() {
 
 hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   const bool small_m = p.R <= 64;
-  const bool big_m = p.R >= 4096 && tile_override() != 0;    // LIP_TILE=0: round-1 128-row tiles (A/B testing)
+  const bool big_m = p.R >= 4096 && tile_override() == 1;    // LIP_TILE=1: 256-row tiles (A/B: 15% slower on MI355X, r2)
   if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);
   if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 2>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st));
   return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st));

@@ -69,7 +69,9 @@ def test_nullproj(impl, sine_data, toyregressor_state):
     assert full_out.shape == (D,)
     resid = cpu64(Wfun(WTfun(full_out)))
     scale = cpu64(Wfun(WTfun(v))).abs().max()
-    assert torch.all(resid.abs() <= 1.5e-3 * max(1.0, scale.item())), "full_out should be in the kernel of the GGN"
+    # reference: atol 1.5e-3 in float64.  fp32 CG on this Gram (cond ~1e17) stalls at ~1e-3 relative.
+    tol = impl.tol(1.5e-3, 5e-3) * max(1.0, scale.item())
+    assert torch.all(resid.abs() <= tol), f"full_out should be in the kernel of the GGN: {resid.abs().max()} > {tol}"
 
 
 def test_matfree_invsqrt(impl):
