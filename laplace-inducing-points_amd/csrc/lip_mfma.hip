@@ -60,16 +60,88 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ As, const f
   }
 }
 
+// Software pipeline shared by the fast kernels: LDS is double buffered and two register tile sets are
+// in flight, so the global loads of K-tile t+2 are issued before the MFMA sweep of tile t and only
+// waited for after the sweep of tile t+1 (a counted vmcnt: the loads are branch-free — masked rows read
+// a device zero page — so the steady-state body is one basic block); one barrier per K-tile.
+//   load(ar, br)            : advance-independent: issue the global loads of the tile under the cursor
+//   store(ar, br, As, Bs)   : write a register tile into one LDS buffer
+//   advance()               : move the cursor to the next tile (only called while tiles remain)
+//   sweep(As, Bs)           : MFMA sweep over one LDS buffer
+template <int AE, int BE, int ASZ, int BSZ, class Load, class Store, class Advance, class Sweep>
+__device__ __forceinline__ void pipelined_k_loop(int T, float* As, float* Bs, Load load, Store store,
+                                                 Advance advance, Sweep sweep) {
+  float aA[AE], bA[BE], aB[AE], bB[BE];
+  load(aA, bA);                                   // tile 0
+  store(aA, bA, As, Bs);
+  if (T > 1) { advance(); load(aA, bA); }         // tile 1 in flight in set A
+  __syncthreads();
+  int t = 0;
+  // steady state, two tiles per trip (static register sets): buffer 0 holds tile t on entry
+  while (t + 3 < T) {
+    advance(); load(aB, bB);                      // tile t+2
+    sweep(As, Bs);                                // tile t
+    store(aA, bA, As + ASZ, Bs + BSZ);            // tile t+1
+    __syncthreads();
+    advance(); load(aA, bA);                      // tile t+3
+    sweep(As + ASZ, Bs + BSZ);                    // tile t+1
+    store(aB, bB, As, Bs);                        // tile t+2
+    __syncthreads();
+    t += 2;
+  }
+  // tail: 1..3 tiles left; set A holds tile t+1 when it exists
+  bool more1 = t + 1 < T;
+  int buf = 0;
+  while (true) {
+    const bool more2 = t + 2 < T;
+    if (more2) { advance(); load(aB, bB); }
+    sweep(As + buf * ASZ, Bs + buf * BSZ);
+    if (more1) store(aA, bA, As + (buf ^ 1) * ASZ, Bs + (buf ^ 1) * BSZ);
+    __syncthreads();
+    if (!more1) break;
+    buf ^= 1; ++t;
+    sweep(As + buf * ASZ, Bs + buf * BSZ);
+    if (more2) store(aB, bB, As + (buf ^ 1) * ASZ, Bs + (buf ^ 1) * BSZ);
+    __syncthreads();
+    if (!more2) break;
+    buf ^= 1; ++t;
+    more1 = false;                                // at most 3 tiles in the tail
+  }
+}
+
+// First-round stagger.  All blocks of a launch have the same duration, so the B blocks co-resident on a
+// CU (and all CUs of the chip) would run their K loops and then their memory-bound epilogues in lockstep:
+// measured on MI355X as a chip-wide HBM burst during which every MFMA pipe idles (23 % of the launch).
+// Delaying the blocks of the first round by phase * (block duration / B) keeps memory and MFMA phases of
+// different blocks overlapped for the rest of the launch.  Speed only: no result depends on it.
+__device__ __forceinline__ void stagger_first_round(int ktiles, int mfma_per_ktile, int blocks_per_cu, int enabled) {
+  if (!enabled || blocks_per_cu <= 1) return;
+  const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+  if (lin >= 256u * (unsigned)blocks_per_cu) return;             // later rounds inherit the stagger
+  const unsigned phase = ((lin >> 8) + lin) % (unsigned)blocks_per_cu;
+  // a block's waves share their SIMD with blocks_per_cu - 1 others: duration ~ B * ktiles * mfma * 64 cycles
+  long long cycles = (long long)phase * ktiles * mfma_per_ktile * 64;
+  while (cycles > 0) { __builtin_amdgcn_s_sleep(127); cycles -= 127 * 64; }
+}
+
 // Fused epilogue shared by the generic and the fast implicit-GEMM kernels.
+// Two phases per 32x32 accumulator tile: first ALL operand loads (xhat, residual, act') are issued into
+// registers, then the results are computed and stored — a load never sits behind a store that might
+// alias it, so the 16 rows of a tile cost one memory round trip instead of sixteen.
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[TM][TN], float* redbuf, int p, int r0,
                                                int n0, int wm, int wn, int lane, int tid) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BN = T::BN;
   const int N = prm.N, R = prm.R;
-  // ---- fused epilogue --------------------------------------------------------------------
   const int l31 = lane & 31, lh = lane >> 5;
   const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
+  const float* __restrict__ xhat = prm.xhat;
+  const float* __restrict__ xhat2 = prm.xhat2;
+  const float* __restrict__ dphi = prm.dphi;
+  const float* __restrict__ res = prm.res ? prm.res + (long long)p * prm.res_ps : nullptr;
+  float* __restrict__ out = prm.out + (long long)p * prm.out_ps;
+  const bool has_e1 = prm.e1 != nullptr, has_r1 = prm.red1 != nullptr;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int cl = (wn * TN + tn) * 32 + l31;
@@ -77,22 +149,35 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
     const bool cv = col < N;
     const float sc = (prm.scale && cv) ? prm.scale[col] : 1.f;
     const float e0v = (prm.e0 && cv) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
-    const float e1v = (prm.e1 && cv) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
+    const float e1v = (has_e1 && cv) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      const int rbase = r0 + (wm * TM + tm) * 32 + 4 * lh;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int r = r0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (r < R && cv) {
-          const unsigned idx = (unsigned)(r * N + col);
-          float v = acc[tm][tn][reg] * sc + e0v;
-          if (prm.e1) v += e1v * prm.xhat[idx];
-          if (prm.res) v += prm.res[(long long)p * prm.res_ps + idx];
-          if (prm.dphi) v *= prm.dphi[idx];
-          prm.out[(long long)p * prm.out_ps + idx] = v;
-          s0 += v;
-          if (prm.red1) s1 += v * prm.xhat2[idx];
+      for (int h = 0; h < 2; ++h) {            // two phases of 8 accumulator rows: loads first, then stores
+        float xv[8], rv[8], dv[8], x2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int reg = 8 * h + q;
+          const int r = rbase + (reg & 3) + 8 * (reg >> 2);
+          const bool ok = cv && r < R;
+          const unsigned idx = ok ? (unsigned)(r * N + col) : 0u;
+          xv[q] = (has_e1 && ok) ? xhat[idx] : 0.f;
+          rv[q] = (res && ok) ? res[idx] : 0.f;
+          dv[q] = (dphi && ok) ? dphi[idx] : 1.f;
+          x2[q] = (has_r1 && ok) ? xhat2[idx] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int reg = 8 * h + q;
+          const int r = rbase + (reg & 3) + 8 * (reg >> 2);
+          if (cv && r < R) {
+            const float v = (acc[tm][tn][reg] * sc + e0v + e1v * xv[q] + rv[q]) * dv[q];
+            out[(unsigned)(r * N + col)] = v;
+            s0 += v;
+            s1 += v * x2[q];
+          }
         }
       }
     }
@@ -299,13 +384,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 //   once (branch-free, host-precomputed segment scalars) and reused for the C/16 K-tiles of the tap;
 //   B and LDS offsets are loop invariant.  ~8 non-MFMA instructions per MFMA instead of ~30.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
+// ABL (timing experiments only, results are wrong for ABL != 0): 1 = no global loads in the K loop,
+// 2 = also no LDS stores / barriers, 3 = MFMA only (operands from registers).
+template <int WM, int WN, int TM, int TN, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
   constexpr int LDA = BM + 2, LDB = BN;
-  __shared__ float As[BK * LDA];
-  __shared__ float Bs[BK * LDB];
+  __shared__ float As[2 * BK * LDA];
+  __shared__ float Bs[2 * BK * LDB];
   __shared__ float redbuf[2 * BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,7 +437,6 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
     bidx[j] = (unsigned)(k * N + n0 + nn);
   }
 
-  float areg[AE], breg[BE];
   int rowoff[AQ];
   bool rowok[AQ];
 
@@ -376,61 +462,91 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
       const int ih = t0h >> ssh, iw = t0w >> ssh;
       rowok[j] = (vi[j] >= 0) && (((t0h | t0w) & smask) == 0) && ((unsigned)ih < (unsigned)sIH) &&
                  ((unsigned)iw < (unsigned)sIW);
-      rowoff[j] = ((vi[j] * sIH + ih) * sIW + iw) * sC + kq4;
+      rowoff[j] = rowok[j] ? ((vi[j] * sIH + ih) * sIW + iw) * sC + kq4 : 0;
     }
   };
-  auto load_tile = [&]() {
+  bool first_load = true;
+  auto load_tile = [&](float (&areg)[AE], float (&breg)[BE]) {
+    if (ABL >= 1 && !first_load) return;
+    first_load = false;
     const float* ap = abase + c0;
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rowok[j]) v = *reinterpret_cast<const float4*>(ap + (unsigned)rowoff[j]);
+      // masked rows read the zero page: no exec branch around the load, so vmcnt waits can be counted
+      const float* src = rowok[j] ? (ap + (unsigned)rowoff[j]) : prm.zeros;
+      const float4 v = *reinterpret_cast<const float4*>(src);
       areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
     }
 #pragma unroll
-    for (int j = 0; j < BE; ++j) breg[j] = bok[j] ? bbase[bidx[j]] : 0.f;
+    for (int j = 0; j < BE; ++j) {
+      const float* src = bok[j] ? (bbase + bidx[j]) : prm.zeros;
+      breg[j] = *src;
+    }
   };
-  auto store_tile = [&]() {
+  bool first_store = true;
+  auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
+    if (ABL >= 2 && !first_store) return;
+    first_store = false;
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
       const int m = (tid + j * NT) >> 2;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) As[(kq4 + t) * LDA + m] = areg[4 * j + t];
+      for (int t = 0; t < 4; ++t) Asb[(kq4 + t) * LDA + m] = areg[4 * j + t];
     }
 #pragma unroll
     for (int j = 0; j < BE; ++j) {
       const int e = tid + j * NT;
       const int k = e / BN, nn = e - k * BN;
-      Bs[k * LDB + nn] = breg[j];
+      Bsb[k * LDB + nn] = breg[j];
     }
   };
-  // move to the next K-tile; false when all segments are consumed
-  auto advance = [&]() -> bool {
+  // move to the next K-tile (callers never advance past the last tile)
+  auto advance = [&]() {
     c0 += BK;
     bbase += BK * N;
     if (c0 == sC) {
       c0 = 0;
       if (++kw == sKW) { kw = 0; ++kh; }
-      if (kh == sKH) {
-        if (++seg == prm.nseg) return false;
-        begin_segment();
-      }
+      if (kh == sKH) { ++seg; begin_segment(); }
       set_tap();
     }
-    return true;
   };
 
+  int ktiles = 0;
+  for (int q = 0; q < prm.nseg; ++q) ktiles += prm.seg[q].Ktot / BK;
+  stagger_first_round(ktiles, TM * TN * (BK / 2), prm.blocks_per_cu, prm.stagger);
   begin_segment();
   set_tap();
-  load_tile();
-  while (true) {
-    __syncthreads();
-    store_tile();
-    __syncthreads();
-    const bool more = advance();
-    if (more) load_tile();
-    mfma_sweep<WM, WN, TM, TN, LDA, LDB>(As, Bs, acc, wm, wn, lane);
-    if (!more) break;
+  if (ABL >= 3) {
+    float fa = (float)tid, fb = (float)lane;
+    f32x16 acc2[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc2[tm][tn] = acc[tm][tn];
+    do {
+#pragma unroll
+      for (int rep = 0; rep < (ABL == 4 ? 4 : 1); ++rep)
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              if (ABL == 5 && (kk & 1)) acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc2[tm][tn], 0, 0, 0);
+              else acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tm][tn], 0, 0, 0);
+            }
+    } while (--ktiles > 0);
+    if (ABL == 5) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] += acc2[tm][tn];
+    }
+  } else {
+    pipelined_k_loop<AE, BE, BK * LDA, BK * LDB>(
+        ktiles, As, Bs, load_tile, store_tile, advance,
+        [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
   }
   igemm_epilogue<WM, WN, TM, TN>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
 }
@@ -572,14 +688,165 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
     const float sc = prm.scale ? prm.scale[col] : 1.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
+      if (prm.ksplit > 1) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + (wm * TM + tm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (m < M) {
-          float* dst = ybase + (unsigned)(m * N + col);
-          const float v = acc[tm][tn][reg] * sc;
-          if (prm.ksplit > 1) atomicAdd(dst, v);
-          else *dst += v;
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = mb + (reg & 3) + 8 * (reg >> 2);
+          if (m < M) atomicAdd(ybase + (unsigned)(m * N + col), acc[tm][tn][reg] * sc);
+        }
+      } else {
+        float old[16];                      // all loads first, then the stores (no load behind a store)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = mb + (reg & 3) + 8 * (reg >> 2);
+          old[reg] = (m < M) ? ybase[(unsigned)(m * N + col)] : 0.f;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = mb + (reg & 3) + 8 * (reg >> 2);
+          if (m < M) ybase[(unsigned)(m * N + col)] = old[reg] + acc[tm][tn][reg] * sc;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient, specialised variant: C % 4 == 0 (float4 gathers), straight-line K loop.
+// Thread-invariant: its kernel tap (kh, kw, ci) and LDS / B offsets.  Per 16-row K-step each float4
+// gather costs two magic-number divisions + a branch-free bounds test.
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP prm) {
+  using T = Tile<WM, WN, TM, TN>;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
+  constexpr int LDA = BM + 4, LDB = BN;
+  constexpr int QPR = BM / 4;
+  __shared__ __attribute__((aligned(16))) float As[2 * BK * LDA];
+  __shared__ float Bs[2 * BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int N = prm.N, M = prm.M;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int p = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  int rows_per = (prm.R + prm.ksplit - 1) / prm.ksplit;
+  rows_per = (rows_per + BK - 1) / BK * BK;
+  const int rbeg = blockIdx.z * rows_per;
+  const int rend = min(prm.R, rbeg + rows_per);
+  if (rbeg >= rend) return;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  // this thread's m (fixed): m = m0 + 4*(tid % QPR) -> tap (kh, kw) and channel ci
+  const int my_m = m0 + 4 * (tid % QPR);
+  const bool mvalid = my_m < M;
+  int thh = 0, tww = 0, ci = 0;
+  if (mvalid) {
+    const int tap = my_m / prm.C;
+    ci = my_m - tap * prm.C;
+    const int kh = tap / prm.KW, kw = tap - kh * prm.KW;
+    thh = kh - prm.pad_h;
+    tww = kw - prm.pad_w;
+  }
+  const int krow0 = tid / QPR;                    // row of quad j inside the K-step: krow0 + j*(NT/QPR)
+  unsigned bidx[BE];
+  int bk[BE];
+  bool bok[BE];
+#pragma unroll
+  for (int j = 0; j < BE; ++j) {
+    const int e = tid + j * NT;
+    const int k = e / BN, nn = e - k * BN;
+    bk[j] = k;
+    bok[j] = (n0 + nn) < N;
+    bidx[j] = (unsigned)(k * N + n0 + nn);
+  }
+
+  const float* gp = prm.g + (long long)p * prm.g_ps + (long long)rbeg * N;
+  const int IH = prm.IH, IW = prm.IW, C = prm.C, stride = prm.stride, OHW = prm.OHW, OW = prm.OW;
+
+  int rk0 = rbeg;
+  auto load_tile = [&](float (&areg)[AE], float (&breg)[BE]) {
+#pragma unroll
+    for (int j = 0; j < AQ; ++j) {
+      const int r = rk0 + krow0 + j * (NT / QPR);
+      const int i = prm.dOHW.div(r), rem = r - i * OHW;
+      const int oh = prm.dOW.div(rem), ow = rem - oh * OW;
+      const int ih = oh * stride + thh, iw = ow * stride + tww;
+      const bool ok = mvalid && (r < rend) && ((unsigned)ih < (unsigned)IH) && ((unsigned)iw < (unsigned)IW);
+      const float* src = ok ? (prm.a + (unsigned)(((i * IH + ih) * IW + iw) * C + ci)) : prm.zeros;
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < BE; ++j) {
+      const float* src = (bok[j] && (rk0 + bk[j]) < rend) ? (gp + bidx[j]) : prm.zeros;
+      breg[j] = *src;
+    }
+  };
+  auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
+#pragma unroll
+    for (int j = 0; j < AQ; ++j) {
+      const int q = tid + j * NT;
+      const int k = q / QPR, mq = q - k * QPR;
+      *reinterpret_cast<float4*>(&Asb[k * LDA + 4 * mq]) =
+          make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < BE; ++j) {
+      const int e = tid + j * NT;
+      const int k = e / BN, nn = e - k * BN;
+      Bsb[k * LDB + nn] = breg[j];
+    }
+  };
+
+  auto advance = [&]() {
+    rk0 += BK;
+    gp += BK * N;
+  };
+  const int ktiles = (rend - rbeg + BK - 1) / BK;
+  stagger_first_round(ktiles, TM * TN * (BK / 2), prm.blocks_per_cu, prm.stagger);
+  pipelined_k_loop<AE, BE, BK * LDA, BK * LDB>(
+      ktiles, As, Bs, load_tile, store_tile, advance,
+      [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* ybase = prm.y + (long long)p * prm.y_ps;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + (wn * TN + tn) * 32 + l31;
+    if (col >= N) continue;
+    const float sc = prm.scale ? prm.scale[col] : 1.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
+      if (prm.ksplit > 1) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = mb + (reg & 3) + 8 * (reg >> 2);
+          if (m < M) atomicAdd(ybase + (unsigned)(m * N + col), acc[tm][tn][reg] * sc);
+        }
+      } else {
+        float old[16];                      // all loads first, then the stores (no load behind a store)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = mb + (reg & 3) + 8 * (reg >> 2);
+          old[reg] = (m < M) ? ybase[(unsigned)(m * N + col)] : 0.f;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = mb + (reg & 3) + 8 * (reg >> 2);
+          if (m < M) ybase[(unsigned)(m * N + col)] = old[reg] + acc[tm][tn][reg] * sc;
         }
       }
     }
@@ -589,6 +856,26 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
 // ------------------------------------------------------------------------------------------
 // launchers: pick the tile shape from the problem shape
 // ------------------------------------------------------------------------------------------
+// 256 bytes of device zeros (per device): the source of masked gather rows in the fast kernels.
+static const float* zero_page() {
+  static float* pages[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!pages[dev]) {
+    float* ptr = nullptr;
+    if (hipMalloc((void**)&ptr, 256) != hipSuccess) return nullptr;
+    if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+    pages[dev] = ptr;
+  }
+  return pages[dev];
+}
+
+static int stagger_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LIP_STAGGER"); v = e ? atoi(e) : 0; }   // measured: no gain (r11) -> off
+  return v;
+}
+
 static bool igemm_fast_ok(const IgemmP& p) {
   for (int s = 0; s < p.nseg; ++s) {
     const SegP& q = p.seg[s];
@@ -604,8 +891,24 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
   const long long tiles = (long long)((p.R + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
   dim3 grid((unsigned)tiles, (unsigned)P, 1);
   static const bool force_generic = getenv("LIP_GENERIC") != nullptr;     // A/B switch
-  if (!force_generic && igemm_fast_ok(p))
-    hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
+  static const int abl = getenv("LIP_ABLATE") ? atoi(getenv("LIP_ABLATE")) : 0;  // timing experiments
+  if (!force_generic && igemm_fast_ok(p)) {
+    static int bpc = 0;
+    if (bpc == 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, igemm_fast_kernel<WM, WN, TM, TN, 0>, T::NT, 0) != hipSuccess || bpc < 1) bpc = 1;
+    }
+    IgemmP q = p;
+    q.zeros = zero_page();
+    if (!q.zeros) return hipErrorOutOfMemory;
+    q.blocks_per_cu = bpc;
+    q.stagger = stagger_enabled();
+    if (abl == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), 0, st, q);
+    else if (abl == 2) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 2>), grid, dim3(T::NT), 0, st, q);
+    else if (abl == 3) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 3>), grid, dim3(T::NT), 0, st, q);
+    else if (abl == 4) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 4>), grid, dim3(T::NT), 0, st, q);
+    else if (abl == 5) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 5>), grid, dim3(T::NT), 0, st, q);
+    else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q);
+  }
   else
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
   return hipGetLastError();
@@ -630,7 +933,21 @@ static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
   using T = Tile<WM, WN, TM, TN>;
   const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
   dim3 grid((unsigned)tiles, (unsigned)P, (unsigned)p.ksplit);
-  hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
+  static const bool force_generic = getenv("LIP_GENERIC") != nullptr;     // A/B switch
+  if (!force_generic && (p.C & 3) == 0 && (((uintptr_t)p.a) & 15) == 0) {
+    static int bpc = 0;
+    if (bpc == 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, wgrad_fast_kernel<WM, WN, TM, TN>, T::NT, 0) != hipSuccess || bpc < 1) bpc = 1;
+    }
+    WgradP q = p;
+    q.zeros = zero_page();
+    if (!q.zeros) return hipErrorOutOfMemory;
+    q.blocks_per_cu = bpc;
+    q.stagger = (p.ksplit == 1) ? stagger_enabled() : 0;
+    hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q);
+  }
+  else
+    hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
   return hipGetLastError();
 }
 
