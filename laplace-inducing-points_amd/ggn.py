@@ -173,7 +173,13 @@ def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
                 E = torch.zeros(e - s, d, device=dev, dtype=torch.float32)
                 E[torch.arange(e - s), torch.arange(s, e)] = 1.0
                 Wm[s:e] = W.rows(E.reshape((e - s,) + inner_shape))
-            WTW = (Wm @ Wm.T)
+            # Gram in float64, chunked over D: an fp32 Gram of a (d, 1e6) factor carries ~1e-4 * max|G| of
+            # rounding noise, enough to push the (numerically zero) eigenvalues of W^T W negative.
+            WTW = torch.zeros(d, d, device=dev, dtype=torch.float64)
+            step = max(1, (256 << 20) // (8 * d))
+            for c in range(0, D, step):
+                blk = Wm[:, c:c + step].double()
+                WTW += blk @ blk.T
         else:
             WTW = torch.empty(d, d, device=dev, dtype=torch.float32)
             for s in range(0, d, bs):
@@ -188,8 +194,8 @@ def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
             e[j] = 1.0
             cols.append(WT(W(e.reshape(inner_shape))).reshape(-1))
         WTW = torch.stack(cols, dim=1)
-    WTW = WTW.to(dtype)
-    return torch.triu(WTW) + torch.triu(WTW, 1).T
+    WTW = torch.triu(WTW) + torch.triu(WTW, 1).T
+    return WTW.to(dtype)
 
 
 def build_WTWz(WT, W_z, inner_shape_z, *, d, dtype=torch.float32, block=64):

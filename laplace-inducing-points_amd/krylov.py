@@ -104,11 +104,15 @@ def tridiag_dense(diag: torch.Tensor, off: torch.Tensor) -> torch.Tensor:
     return T
 
 
-def dense_funm_sym_eigh(matfun: Callable, clip_min: Optional[float] = None):
+def dense_funm_sym_eigh(matfun: Callable, clip_min: Optional[float] = None, floor: Optional[float] = None):
     """Dense f(T) through eigh; ``clip_min=1.0`` reproduces the reference's monkey-patch
-    (``src/matfree_monkeypatch.py:8-22``, clip at ``:19``).  Batched over leading dimensions."""
+    (``src/matfree_monkeypatch.py:8-22``, clip at ``:19``).  ``floor`` is a known lower bound of the
+    operator's spectrum (alpha for alpha I + PSD): fp32 Ritz values that rounding pushed below it are
+    raised to it instead of producing NaN under x^(-1/2).  Batched over leading dimensions."""
     def fun(T):
         ev, U = torch.linalg.eigh(T)
+        if floor is not None:
+            ev = torch.clamp(ev, min=floor)
         if clip_min is not None:
             ev = torch.clamp(ev, min=clip_min)
         return (U * matfun(ev).unsqueeze(-2)) @ U.transpose(-1, -2)

@@ -14,6 +14,10 @@ Decisions on the reference's defects (documented in DESIGN.md):
   * ``clip_min``: the reference evaluates f(max(lambda, 1)) through its monkey-patched eigh
     (``src/matfree_monkeypatch.py:19``); default here is the mathematics (``None``); pass
     ``clip_min=REFERENCE_CLIP_MIN`` for the reference's behaviour.
+  * ``method``: the reference evaluates f(alpha I_d + beta W^T W) u by a min(2M, d)-step Lanczos
+    (``"lanczos"``, kept, on the HIP Krylov kernels).  At the CIFAR config that matrix has condition
+    number ~1e9 and 2M = 100 steps do not resolve x^(-1/2) on it, so the default is the exact
+    evaluation through one eigendecomposition of the d x d matrix (``"eigh"``) — cheaper as well.
   * (W^T W) is singular for the classifier (rank K-1 per example, §4.1-5) and whenever d > D; the
     reference calls ``solve`` on it.  Here the Moore-Penrose pseudo-inverse is used (identical when
     W^T W is invertible).
@@ -40,12 +44,21 @@ def _seed(key) -> int:
     return int(key)
 
 
-def _pinv_sym(G: torch.Tensor, rtol: float = 1e-6) -> torch.Tensor:
-    """Pseudo-inverse of the symmetric PSD Gram matrix (float64 on device; d <= ~1000)."""
+GRAM_RTOL = 1e-6
+
+
+def _psd_and_pinv(G: torch.Tensor, rtol: float = GRAM_RTOL):
+    """Project the symmetric Gram matrix onto the PSD cone and return (G_psd, G^+) in float64.
+    Eigenvalues <= rtol * max are treated as zero (the classifier's W^T W has rank M (K-1))."""
     ev, U = torch.linalg.eigh(G.double())
     keep = ev > rtol * ev.max().clamp_min(1e-300)
+    evp = torch.where(keep, ev, torch.zeros_like(ev))
     inv = torch.where(keep, 1.0 / ev.clamp_min(1e-300), torch.zeros_like(ev))
-    return ((U * inv) @ U.T)
+    return (U * evp) @ U.T, (U * inv) @ U.T
+
+
+def _pinv_sym(G: torch.Tensor, rtol: float = GRAM_RTOL) -> torch.Tensor:
+    return _psd_and_pinv(G, rtol)[1]
 
 
 class _SamplerParts:
@@ -60,16 +73,19 @@ class _SamplerParts:
         self.beta = N / M
         self.inner = self.WTfun.out_shape
         self.d = math.prod(self.inner)
-        self.WTW = build_WTW(self.Wfun, self.WTfun, self.inner, self.d, dtype=torch.float32, block=2)   # :77
-        self.G_pinv = _pinv_sym(self.WTW).float().contiguous()
-        self.A_d = (self.alpha * torch.eye(self.d, device=eng.device, dtype=torch.float32) + self.beta * self.WTW).contiguous()
+        G64 = build_WTW(self.Wfun, self.WTfun, self.inner, self.d, dtype=torch.float64, block=2)        # :77
+        G_psd, G_pinv = _psd_and_pinv(G64)
+        self.WTW = G_psd.float().contiguous()
+        self.G_pinv = G_pinv.float().contiguous()
+        A64 = self.alpha * torch.eye(self.d, device=eng.device, dtype=torch.float64) + self.beta * G_psd
+        self.A_d = A64.float().contiguous()
         self.depth = min(2 * M, self.d)                                                     # :114
         self.clip_min, self.method = clip_min, method
         f = lambda x: 1.0 / torch.sqrt(x)
         if method == "lanczos":
-            self.funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(f, clip_min), self.depth)   # :113-115
+            self.funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(f, clip_min, floor=self.alpha), self.depth)   # :113-115
         elif method == "eigh":
-            self.fA = krylov.dense_funm_sym_eigh(f, clip_min)(self.A_d.double()).float().contiguous()
+            self.fA = krylov.dense_funm_sym_eigh(f, clip_min, floor=self.alpha)(A64).float().contiguous()
         else:
             raise ValueError("method must be 'lanczos' or 'eigh'")
 
@@ -91,7 +107,7 @@ class _SamplerParts:
 
 
 def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None, num_proj_steps=1,
-                   clip_min: Optional[float] = None, method: str = "lanczos"):
+                   clip_min: Optional[float] = None, method: str = "eigh"):
     """``src/sample.py:55-145``.  Returns a block operator v -> A^(-1/2) v on (D,) or (S, D).
     (``key`` / ``num_proj_steps`` select the reference's alternating-projection branch, which it
     disables itself — ``:150`` forces ``key=None`` because the branch returns NaN)"""
@@ -104,7 +120,7 @@ def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None,
 
 
 def sample(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None, num_proj_steps=10,
-           clip_min: Optional[float] = None, method: str = "lanczos", block: int = 256):
+           clip_min: Optional[float] = None, method: str = "eigh", block: int = 256):
     """``src/sample.py:148-156``: ``num_samples`` zero-mean draws A^(-1/2) eps, eps ~ N(0, I) -> (S, D).
     (theta_MAP is *not* added, as in the reference: ``:153-154``.)  eps comes from the in-kernel
     Philox generator seeded by ``key``; bit parity with JAX's threefry is not attempted."""
@@ -130,7 +146,8 @@ def sample_lanczos(state, Z, D, alpha, key, model_type, num_samples=1, full_set_
     N = full_set_size or M
     scale = N / M * (math.exp(-float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0)
     matvec = lambda V: eng.ggn_vp(V, scale, float(alpha))
-    funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(lambda x: 1.0 / torch.sqrt(x), clip_min), num_matvecs)
+    funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(lambda x: 1.0 / torch.sqrt(x), clip_min, floor=float(alpha)),
+                                   num_matvecs)
     Eps = krylov.fill_normal(num_samples, eng.D, _seed(key) * 1000003, eng.device)
     return funm(matvec, Eps)
 
@@ -164,7 +181,7 @@ def sample_dense(state, Z, D, alpha, key, model_type, num_samples=1, full_set_si
 
 
 def sample_both(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None,
-                clip_min: Optional[float] = None, method: str = "lanczos"):
+                clip_min: Optional[float] = None, method: str = "eigh"):
     """``src/sample.py:168-178``: the matrix-free and the dense sampler on the same noise."""
     fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, clip_min=clip_min, method=method)
     Eps = krylov.fill_normal(num_samples, fun.engine.D, _seed(key) * 1000003, fun.engine.device)

@@ -119,6 +119,32 @@ def compute_ggn_vp(state, Z, model_type, full_set_size=None):
     return ggn_vp
 
 
+def compute_ggn_vp_batched(state, Z, model_type, full_set_size=None):
+    """Same arithmetic as :func:`compute_ggn_vp` with the example loop batched: ONE forward-mode pass and
+    ONE reverse-mode pass over all M examples (variant (b) of BASELINE.md §3 — the fair CPU baseline; the
+    reference's ``fori_loop`` (``src/ggn.py:144``) is variant (a))."""
+    flat_params, unravel_fn = flatten_nn_params(state.params)
+    M = Z.shape[0]
+    N = full_set_size or M
+    recal_term = N / M
+    if model_type == "regressor":
+        recal_term = recal_term * torch.exp(-state.params["logvar"]["logvar"])
+    model_fun = _model_fun(state, unravel_fn, model_type)
+    f = lambda flatp: model_fun(flatp, Z).reshape(M, -1)
+
+    def ggn_vp(v):
+        out, jv = jvp(f, (flat_params,), (v,))
+        if model_type == "classifier":
+            probs = torch.softmax(out, dim=-1)
+            hv = probs * jv - probs * (probs * jv).sum(-1, keepdim=True)
+        else:
+            hv = jv
+        _, vjp_fn = vjp(f, flat_params)
+        return vjp_fn(hv)[0] * recal_term
+
+    return ggn_vp
+
+
 def compute_ggn_dense(state, Z, model_type, full_set_size=None):
     """``src/ggn.py:149-193``: returns ``(GGN, flat_params, unravel_fn)``."""
     flat_params, unravel_fn = flatten_nn_params(state.params)

@@ -77,3 +77,14 @@ def test_ggnvp_I_vs_full_ggn_classifier(impl, classification_2d_data, classifier
     if impl.is_hip:
         full, *_ = impl.ggn.compute_ggn_dense(st, Xd, model_type="classifier")
         assert torch.allclose(cpu64(full), full_ref, atol=2e-5, rtol=1e-4)
+
+
+def test_batched_cpu_baseline_equals_literal(classification_2d_data, classifier_state):
+    """The example-batched CPU restatement timed by bench.py computes the same GGN-vp as the literal loop."""
+    import oracle.ggn as og
+    X, y = classification_2d_data
+    X = X[::10]
+    v = torch.randn(354, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    a = og.compute_ggn_vp(classifier_state, X, "classifier", full_set_size=77)(v)
+    b = og.compute_ggn_vp_batched(classifier_state, X, "classifier", full_set_size=77)(v)
+    assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
