@@ -952,7 +952,10 @@ static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
 }
 
 hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
-  const bool small_m = p.M <= 64;
+  // 64-row tiles when they waste fewer padded rows of M = KH*KW*Cin than 128-row tiles (M = 288: 320 vs 384)
+  static const int wg64 = getenv("LIP_WG64") ? atoi(getenv("LIP_WG64")) : 0;   // measured r15: 54.6 vs 52.4 ms -> off
+  const int waste128 = (p.M + 127) / 128 * 128 - p.M, waste64 = (p.M + 63) / 64 * 64 - p.M;
+  const bool small_m = p.M <= 64 || (wg64 && waste64 < waste128);
   if (p.N > 64) return small_m ? run_wgrad<2, 2, 1, 2>(p, P, st) : run_wgrad<2, 2, 2, 2>(p, P, st);
   if (p.N > 32) return small_m ? run_wgrad<2, 2, 1, 1>(p, P, st) : run_wgrad<4, 1, 1, 2>(p, P, st);
   return small_m ? run_wgrad<2, 1, 1, 1>(p, P, st) : run_wgrad<4, 1, 1, 1>(p, P, st);

@@ -24,17 +24,37 @@ def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
 class ShardedDataSum:
     """Wrap a rank-local block operator (the partial sum over this rank's examples) into the global one.
 
-    ``local(V) -> (P, D)`` must already carry the global recalibration N/M_total (so that the partial sums
-    simply add) but NOT the prior term alpha*V, which is added once after the reduction."""
+    ``local(V[, out=])`` -> (P, D) must already carry the global recalibration N/M_total (so that the partial
+    sums simply add) but NOT the prior term alpha*V, which is added once after the reduction.
 
-    def __init__(self, local: Callable[[torch.Tensor], torch.Tensor], alpha: float = 0.0,
-                 group: Optional[dist.ProcessGroup] = None):
-        self.local, self.alpha, self.group = local, float(alpha), group
+    With ``chunk`` set, the probe block is processed in chunks and the all-reduce of chunk c runs (on RCCL's
+    stream) while chunk c+1 is being computed: the collective is per-link bound over xGMI and uses few CUs,
+    so it hides behind the MFMA-bound sweep.  Still exactly one all-reduce per matvec *per probe*."""
+
+    def __init__(self, local: Callable[..., torch.Tensor], alpha: float = 0.0,
+                 group: Optional[dist.ProcessGroup] = None, chunk: Optional[int] = None):
+        self.local, self.alpha, self.group, self.chunk = local, float(alpha), group, chunk
+
+    def _world(self) -> int:
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
 
     def __call__(self, V: torch.Tensor) -> torch.Tensor:
-        Y = self.local(V)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self.group)      # the one collective per matvec
+        world = self._world()
+        if world > 1 and self.chunk and V.dim() == 2 and V.shape[0] > self.chunk:
+            Y = torch.empty_like(V)
+            pending = []
+            for c0 in range(0, V.shape[0], self.chunk):
+                c1 = min(V.shape[0], c0 + self.chunk)
+                self.local(V[c0:c1], out=Y[c0:c1])
+                pending.append(dist.all_reduce(Y[c0:c1], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for h in pending:
+                h.wait()
+        else:
+            Y = self.local(V)
+            if world > 1:
+                dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self.group)      # the one collective per matvec
         if self.alpha != 0.0:
             Y = Y.add_(V.reshape(Y.shape), alpha=self.alpha) if Y.is_cuda else Y + self.alpha * V.reshape(Y.shape)
         return Y

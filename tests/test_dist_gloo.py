@@ -32,8 +32,16 @@ def _worker(rank, world, port, ret):
     # local partial sum carries the GLOBAL recalibration N / n_total: oracle's factor is N/M_local -> rescale
     vp_loc = compute_ggn_vp(st, Z[lo:hi], "classifier", full_set_size=N)
     fix = (hi - lo) / 7.0
-    op = ShardedDataSum(lambda B: torch.stack([vp_loc(v) for v in B]) * fix, alpha)
+    def local(B, out=None):
+        r = torch.stack([vp_loc(v) for v in B]) * fix
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+    op = ShardedDataSum(local, alpha)
     Y = op(V)
+    Yc = ShardedDataSum(local, alpha, chunk=2)(V)          # chunked, async all-reduce per chunk
+    assert torch.allclose(Y, Yc, rtol=1e-13, atol=1e-13)
     vp_full = compute_ggn_vp(st, Z, "classifier", full_set_size=N)
     ref = torch.stack([vp_full(v) + alpha * v for v in V])
     err = (Y - ref).abs().max().item()
