@@ -86,12 +86,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+        backend = os.environ.get("LIP_DIST_BACKEND", "nccl")      # "gloo": rehearsal of N ranks on one card
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     net = ResNet1M(10)
     state = create_state(net, seed=1231231234, dtype=torch.float32)           # config/scale/resnet1_cifar10.yml:5
