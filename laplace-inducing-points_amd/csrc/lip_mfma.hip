@@ -120,19 +120,22 @@ __device__ __forceinline__ void stagger_first_round(int ktiles, int mfma_per_kti
   if (lin >= 256u * (unsigned)blocks_per_cu) return;             // later rounds inherit the stagger
   const unsigned phase = ((lin >> 8) + lin) % (unsigned)blocks_per_cu;
   // a block's waves share their SIMD with blocks_per_cu - 1 others: duration ~ B * ktiles * mfma * 64 cycles
-  long long cycles = (long long)phase * ktiles * mfma_per_ktile * 64;
+  long long cycles = (long long)phase * ktiles * mfma_per_ktile * 64 * enabled;   // enabled > 1: exaggerated (experiments)
   while (cycles > 0) { __builtin_amdgcn_s_sleep(127); cycles -= 127 * 64; }
 }
 
 // Fused epilogue shared by the generic and the fast implicit-GEMM kernels.
-// Two phases per 32x32 accumulator tile: first ALL operand loads (xhat, residual, act') are issued into
-// registers, then the results are computed and stored — a load never sits behind a store that might
-// alias it, so the 16 rows of a tile cost one memory round trip instead of sixteen.
+// The accumulators are drained in "phases" of 8 rows of one 32x32 tile.  Each phase needs operand loads
+// (xhat, residual, act') before its stores; phases are software pipelined with two register sets, so the
+// loads of phase t+1 are in flight while phase t is computed and stored — the 2..8 phases of a wave cost
+// about one loaded-memory latency in total instead of one each (measured: the serial form kept a block's
+// slot idle for ~16 % of the launch).
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[TM][TN], float* redbuf, int p, int r0,
                                                int n0, int wm, int wn, int lane, int tid) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BN = T::BN;
+  constexpr int NPH = TM * TN * 2;                 // phases: (tn, tm, half)
   const int N = prm.N, R = prm.R;
   const int l31 = lane & 31, lh = lane >> 5;
   const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
@@ -142,55 +145,75 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
   const float* __restrict__ res = prm.res ? prm.res + (long long)p * prm.res_ps : nullptr;
   float* __restrict__ out = prm.out + (long long)p * prm.out_ps;
   const bool has_e1 = prm.e1 != nullptr, has_r1 = prm.red1 != nullptr;
+
+  float sc[TN], e0v[TN], e1v[TN], s0[TN], s1[TN];
+  bool cv[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int cl = (wn * TN + tn) * 32 + l31;
-    const int col = n0 + cl;
-    const bool cv = col < N;
-    const float sc = (prm.scale && cv) ? prm.scale[col] : 1.f;
-    const float e0v = (prm.e0 && cv) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
-    const float e1v = (has_e1 && cv) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int rbase = r0 + (wm * TM + tm) * 32 + 4 * lh;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {            // two phases of 8 accumulator rows: loads first, then stores
-        float xv[8], rv[8], dv[8], x2[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int reg = 8 * h + q;
-          const int r = rbase + (reg & 3) + 8 * (reg >> 2);
-          const bool ok = cv && r < R;
-          const unsigned idx = ok ? (unsigned)(r * N + col) : 0u;
-          xv[q] = (has_e1 && ok) ? xhat[idx] : 0.f;
-          rv[q] = (res && ok) ? res[idx] : 0.f;
-          dv[q] = (dphi && ok) ? dphi[idx] : 1.f;
-          x2[q] = (has_r1 && ok) ? xhat2[idx] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int reg = 8 * h + q;
-          const int r = rbase + (reg & 3) + 8 * (reg >> 2);
-          if (cv && r < R) {
-            const float v = (acc[tm][tn][reg] * sc + e0v + e1v * xv[q] + rv[q]) * dv[q];
-            out[(unsigned)(r * N + col)] = v;
-            s0 += v;
-            s1 += v * x2[q];
-          }
-        }
-      }
-    }
-    if (do_red) {
-      s0 += __shfl_xor(s0, 32, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      if (lh == 0) {
-        atomicAdd(&redbuf[cl], s0);
-        atomicAdd(&redbuf[BN + cl], s1);
-      }
-    }
+    const int col = n0 + (wn * TN + tn) * 32 + l31;
+    cv[tn] = col < N;
+    sc[tn] = (prm.scale && cv[tn]) ? prm.scale[col] : 1.f;
+    e0v[tn] = (prm.e0 && cv[tn]) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
+    e1v[tn] = (has_e1 && cv[tn]) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
+    s0[tn] = 0.f; s1[tn] = 0.f;
   }
+
+  // phase ph -> (tn, tm, h); row of accumulator register reg = 8*h + q
+  auto row_of = [&](int ph, int q) -> int {
+    const int tm = (ph >> 1) % TM, h = ph & 1, reg = 8 * h + q;
+    return r0 + (wm * TM + tm) * 32 + 4 * lh + (reg & 3) + 8 * (reg >> 2);
+  };
+  auto issue = [&](int ph, float (&xv)[8], float (&rv)[8], float (&dv)[8], float (&x2)[8]) {
+    const int tn = ph / (2 * TM);
+    const int col = n0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = row_of(ph, q);
+      const bool ok = cv[tn] && r < R;
+      const unsigned idx = ok ? (unsigned)(r * N + col) : 0u;     // clamped: loads stay unconditional
+      xv[q] = has_e1 ? xhat[idx] : 0.f;
+      rv[q] = res ? res[idx] : 0.f;
+      dv[q] = dphi ? dphi[idx] : 1.f;
+      x2[q] = has_r1 ? xhat2[idx] : 0.f;
+    }
+  };
+  auto finish = [&](int ph, const float (&xv)[8], const float (&rv)[8], const float (&dv)[8], const float (&x2)[8]) {
+    const int tn = ph / (2 * TM), tm = (ph >> 1) % TM, h = ph & 1;
+    const int col = n0 + (wn * TN + tn) * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = row_of(ph, q);
+      if (cv[tn] && r < R) {
+        const float v = (acc[tm][tn][8 * h + q] * sc[tn] + e0v[tn] + e1v[tn] * xv[q] + rv[q]) * dv[q];
+        out[(unsigned)(r * N + col)] = v;
+        s0[tn] += v;
+        s1[tn] += v * x2[q];
+      }
+    }
+  };
+
+  float xA[8], rA[8], dA[8], yA[8], xB[8], rB[8], dB[8], yB[8];
+  issue(0, xA, rA, dA, yA);
+#pragma unroll
+  for (int ph = 0; ph < NPH; ph += 2) {
+    issue(ph + 1, xB, rB, dB, yB);                  // NPH is even: phase ph+1 always exists
+    finish(ph, xA, rA, dA, yA);
+    if (ph + 2 < NPH) issue(ph + 2, xA, rA, dA, yA);
+    finish(ph + 1, xB, rB, dB, yB);
+  }
+
   if (do_red) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int cl = (wn * TN + tn) * 32 + l31;
+      float a0 = s0[tn], a1 = s1[tn];
+      a0 += __shfl_xor(a0, 32, 64);
+      a1 += __shfl_xor(a1, 32, 64);
+      if (lh == 0) {
+        atomicAdd(&redbuf[cl], a0);
+        atomicAdd(&redbuf[BN + cl], a1);
+      }
+    }
     __syncthreads();
     for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
@@ -517,8 +540,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   stagger_first_round(ktiles, TM * TN * (BK / 2), prm.blocks_per_cu, prm.stagger);
   begin_segment();
   set_tap();
-  if (ABL >= 3) {
+  if (ABL >= 3) {   // 3: MFMA only; 4: 4x the MFMAs; 5: two accumulators; 6: MFMA only and no epilogue; 7: randomised loop length
     float fa = (float)tid, fb = (float)lane;
+    if (ABL == 7) {   // per-block K-loop length in [0.5, 1.5] x nominal (mean 1): breaks any lockstep between blocks
+      unsigned h = (blockIdx.x * 2654435761u) ^ (blockIdx.y * 40503u);
+      h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+      ktiles = max(1, (int)(ktiles * (0.5f + (float)(h & 1023) / 1023.0f)));
+    }
     f32x16 acc2[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -533,7 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-              if (ABL == 5 && (kk & 1)) acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc2[tm][tn], 0, 0, 0);
+              if ((ABL == 5) && (kk & 1)) acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc2[tm][tn], 0, 0, 0);
               else acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tm][tn], 0, 0, 0);
             }
     } while (--ktiles > 0);
@@ -547,6 +575,17 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
     pipelined_k_loop<AE, BE, BK * LDA, BK * LDB>(
         ktiles, As, Bs, load_tile, store_tile, advance,
         [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
+  }
+  if (ABL == 6) {                                    // keep the accumulators live with one store per lane
+    float t = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[tm][tn][r];
+    if (t == 123.456f) prm.out[0] = t;
+    return;
   }
   igemm_epilogue<WM, WN, TM, TN>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
 }
@@ -898,6 +937,8 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, igemm_fast_kernel<WM, WN, TM, TN, 0>, T::NT, 0) != hipSuccess || bpc < 1) bpc = 1;
     }
     IgemmP q = p;
+    static const bool nored = getenv("LIP_NORED") != nullptr;      // timing experiment: drop the reductions
+    if (nored) { q.red0 = nullptr; q.red1 = nullptr; }
     q.zeros = zero_page();
     if (!q.zeros) return hipErrorOutOfMemory;
     q.blocks_per_cu = bpc;
@@ -907,6 +948,8 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
     else if (abl == 3) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 3>), grid, dim3(T::NT), 0, st, q);
     else if (abl == 4) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 4>), grid, dim3(T::NT), 0, st, q);
     else if (abl == 5) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 5>), grid, dim3(T::NT), 0, st, q);
+    else if (abl == 6) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 6>), grid, dim3(T::NT), 0, st, q);
+    else if (abl == 7) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 7>), grid, dim3(T::NT), 0, st, q);
     else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q);
   }
   else

@@ -80,16 +80,54 @@ def _logvar(state):
     return float(torch.as_tensor(state.params["logvar"]["logvar"]).detach().cpu())
 
 
-def compute_ggn_vp(state, Z, model_type, full_set_size=None):
+def materialize_factor(eng: LinearizedNet, c: float = 1.0, block: Optional[int] = None) -> torch.Tensor:
+    """Wm (d, D) with rows c * J_i^T L_i e_k — the square-root factor W^T of the GGN (``src/ggn.py:9-93``)
+    written out: d = M K engine rows (one backward sweep with the one-hot block as cotangents)."""
+    d = eng.n * eng.K
+    bs = block or max(1, min(d, (2 << 30) // (4 * eng.D)))
+    Wm = torch.empty(d, eng.D, device=eng.device, dtype=torch.float32)
+    for s in range(0, d, bs):
+        e = min(d, s + bs)
+        E = torch.zeros(e - s, d, device=eng.device, dtype=torch.float32)
+        E[torch.arange(e - s), torch.arange(s, e)] = 1.0
+        Wm[s:e] = eng.vjp(E.reshape(e - s, eng.n, eng.K), "l", c)
+    return Wm
+
+
+FACTOR_BYTES_LIMIT = 64 << 30
+
+
+def compute_ggn_vp(state, Z, model_type, full_set_size=None, mode: str = "matfree"):
     """``src/ggn.py:97-146``: v -> (N/M) sum_i J_i^T H_i J_i v (x exp(-logvar) for the regressor,
-    ``:111-113``).  One fused tangent-forward -> output-Hessian -> backward sweep per probe block."""
+    ``:111-113``).
+
+    ``mode="matfree"`` (default, the reference's algorithm): one fused tangent-forward -> output-Hessian ->
+    backward sweep per probe block, 8 MACs_fwd FLOP per (example, probe), nothing of size M x D stored.
+    ``mode="factor"``: when the factor Wm (d = M K rows of D floats) fits in HBM — the inducing-point regime
+    M << N — the GGN is Wm^T Wm and a block matvec is two plain GEMMs, 4 d D FLOP per probe (30x fewer
+    than matrix-free at the CIFAR config: d = 500, D = 1.08 M) after a one-off d-row backward sweep.
+    ``mode="auto"`` picks "factor" when d * D * 4 B <= 64 GiB."""
     eng = get_engine(state, Z, model_type)
     M = Z.shape[0]
     N = full_set_size or M
     recal_term = N / M
     if model_type == "regressor":
         recal_term *= math.exp(-_logvar(state))
-    return BlockOperator(lambda V: eng.ggn_vp(V, recal_term, 0.0), (eng.D,), (eng.D,), eng, "ggn_vp")
+    if mode == "auto":
+        mode = "factor" if eng.n * eng.K * eng.D * 4 <= FACTOR_BYTES_LIMIT else "matfree"
+    if mode == "matfree":
+        return BlockOperator(lambda V: eng.ggn_vp(V, recal_term, 0.0), (eng.D,), (eng.D,), eng, "ggn_vp")
+    if mode != "factor":
+        raise ValueError("mode must be 'matfree', 'factor' or 'auto'")
+    Wm = materialize_factor(eng, math.sqrt(recal_term))
+
+    def apply(V):
+        Vb = V.to(device=eng.device, dtype=torch.float32)
+        return (Vb @ Wm.T) @ Wm          # plain library GEMMs (rocBLAS): (P, d) then (P, D)
+
+    op = BlockOperator(apply, (eng.D,), (eng.D,), eng, "ggn_vp[factor]")
+    op.factor = Wm
+    return op
 
 
 def compute_W_vps(state, Z, model_type, full_set_size=None, blockwise=False):

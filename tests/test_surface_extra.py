@@ -135,3 +135,21 @@ def test_cifar_resnet1m_full_size_properties():
     Gm = V @ Y.T                                       # (16, 16) = V G V^T
     assert torch.allclose(Gm, Gm.T, rtol=1e-3, atol=1e-3 * Gm.abs().max().item())
     assert torch.linalg.eigvalsh(0.5 * (Gm + Gm.T).double()).min() > -1e-3 * Gm.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_factor_mode_equals_matrix_free(classification_2d_data, classifier_state):
+    """compute_ggn_vp(mode="factor") (materialised W, two GEMMs) == the matrix-free sweep == the oracle."""
+    import src.ggn as hg
+    X, y = classification_2d_data
+    X = X[::10]
+    st = classifier_state.to(device="cuda", dtype=torch.float32)
+    Xd = X.cuda().float()
+    V = torch.randn(5, 354, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    a = hg.compute_ggn_vp(st, Xd, "classifier", full_set_size=77)(V.cuda().float())
+    b = hg.compute_ggn_vp(st, Xd, "classifier", full_set_size=77, mode="factor")(V.cuda().float())
+    c = hg.compute_ggn_vp(st, Xd, "classifier", full_set_size=77, mode="auto")(V.cuda().float())
+    ref_vp = og.compute_ggn_vp(classifier_state, X, "classifier", full_set_size=77)
+    ref = torch.stack([ref_vp(v) for v in V])
+    for out in (a, b, c):
+        assert torch.allclose(cpu64(out), ref, rtol=2e-4, atol=2e-4 * ref.abs().max().item())
