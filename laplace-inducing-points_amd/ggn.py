@@ -97,6 +97,18 @@ def materialize_factor(eng: LinearizedNet, c: float = 1.0, block: Optional[int] 
 FACTOR_BYTES_LIMIT = 64 << 30
 
 
+def gram_from_factor(Wm: torch.Tensor) -> torch.Tensor:
+    """Wm Wm^T (d, d) accumulated in float64, chunked over D: an fp32 Gram of a (d, 1e6) factor carries
+    ~1e-4 * max|G| of rounding noise, enough to push the (numerically zero) eigenvalues of W^T W negative."""
+    d, D = Wm.shape
+    G = torch.zeros(d, d, device=Wm.device, dtype=torch.float64)
+    step = max(1, (256 << 20) // (8 * d))
+    for c in range(0, D, step):
+        blk = Wm[:, c:c + step].double()
+        G += blk @ blk.T
+    return G
+
+
 def compute_ggn_vp(state, Z, model_type, full_set_size=None, mode: str = "matfree"):
     """``src/ggn.py:97-146``: v -> (N/M) sum_i J_i^T H_i J_i v (x exp(-logvar) for the regressor,
     ``:111-113``).
@@ -211,13 +223,7 @@ def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
                 E = torch.zeros(e - s, d, device=dev, dtype=torch.float32)
                 E[torch.arange(e - s), torch.arange(s, e)] = 1.0
                 Wm[s:e] = W.rows(E.reshape((e - s,) + inner_shape))
-            # Gram in float64, chunked over D: an fp32 Gram of a (d, 1e6) factor carries ~1e-4 * max|G| of
-            # rounding noise, enough to push the (numerically zero) eigenvalues of W^T W negative.
-            WTW = torch.zeros(d, d, device=dev, dtype=torch.float64)
-            step = max(1, (256 << 20) // (8 * d))
-            for c in range(0, D, step):
-                blk = Wm[:, c:c + step].double()
-                WTW += blk @ blk.T
+            WTW = gram_from_factor(Wm)
         else:
             WTW = torch.empty(d, d, device=dev, dtype=torch.float32)
             for s in range(0, d, bs):

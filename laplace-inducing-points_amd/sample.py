@@ -30,7 +30,8 @@ from typing import Optional
 import torch
 
 from . import krylov
-from .ggn import BlockOperator, build_WTW, compute_ggn_vp, compute_W_vps
+from .ggn import (FACTOR_BYTES_LIMIT, BlockOperator, build_WTW, compute_ggn_vp, compute_W_vps, gram_from_factor,
+                  materialize_factor)
 from .utils import flatten_nn_params
 
 REFERENCE_CLIP_MIN = 1.0
@@ -73,7 +74,16 @@ class _SamplerParts:
         self.beta = N / M
         self.inner = self.WTfun.out_shape
         self.d = math.prod(self.inner)
-        G64 = build_WTW(self.Wfun, self.WTfun, self.inner, self.d, dtype=torch.float64, block=2)        # :77
+        # In the inducing-point regime the factor Wm (d, D) fits in HBM: materialise it once (d backward rows),
+        # take the Gram from it and apply W^T / W as plain GEMMs.  Otherwise stay matrix-free throughout.
+        self.Wm = None
+        if self.d * eng.D * 4 <= FACTOR_BYTES_LIMIT:
+            c = math.sqrt(1.0) * (math.exp(-0.5 * float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0)
+            self.Wm = materialize_factor(eng, c)
+            G64 = gram_from_factor(self.Wm)
+            G64 = torch.triu(G64) + torch.triu(G64, 1).T                                                 # :227
+        else:
+            G64 = build_WTW(self.Wfun, self.WTfun, self.inner, self.d, dtype=torch.float64, block=2)    # :77
         G_psd, G_pinv = _psd_and_pinv(G64)
         self.WTW = G_psd.float().contiguous()
         self.G_pinv = G_pinv.float().contiguous()
@@ -98,11 +108,18 @@ class _SamplerParts:
     def apply(self, V: torch.Tensor) -> torch.Tensor:
         """rows of V (S, D) -> A^(-1/2) V"""
         S = V.shape[0]
-        U = self.WTfun.rows(V).reshape(S, self.d)                                          # W^T v
+        if self.Wm is not None:
+            U = V @ self.Wm.T                                                              # W^T v as a GEMM
+        else:
+            U = self.WTfun.rows(V).reshape(S, self.d)                                      # W^T v, matrix-free
         x1 = self.f_small(U) @ self.G_pinv                                                 # :130-138
         x2 = U @ self.G_pinv                                                               # :78-84
         a = 1.0 / math.sqrt(self.alpha)
-        out = self.Wfun.rows((x1 - a * x2).reshape((S,) + self.inner))                     # one W sweep
+        X = (x1 - a * x2).contiguous()
+        if self.Wm is not None:
+            out = X @ self.Wm                                                              # W x as a GEMM
+        else:
+            out = self.Wfun.rows(X.reshape((S,) + self.inner))                             # one W sweep
         return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
 
 
