@@ -123,12 +123,31 @@ class _SamplerParts:
         return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
 
 
+_PARTS_CACHE = {}
+
+
+def _cached_parts(state, Z, D, alpha, model_type, full_set_size, clip_min, method):
+    """One factor / Gram / f(A) build per (engine binding, alpha, N, clip, method): evaluation loops call
+    ``predict_lla_scalable`` once per test batch with the same (state, Z) (``scale_experiments/evaluate.py:103``),
+    and the reference rebuilds everything each time (``src/lla.py:137``)."""
+    from .ggn import get_engine
+    eng = get_engine(state, Z, model_type)
+    key = (id(eng), float(alpha), full_set_size, clip_min, method)
+    parts = _PARTS_CACHE.get(key)
+    if parts is None or parts.eng is not eng:
+        parts = _SamplerParts(state, Z, D, alpha, model_type, full_set_size, clip_min, method)
+        if len(_PARTS_CACHE) >= 2:
+            _PARTS_CACHE.pop(next(iter(_PARTS_CACHE)))
+        _PARTS_CACHE[key] = parts
+    return parts
+
+
 def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None, num_proj_steps=1,
                    clip_min: Optional[float] = None, method: str = "eigh"):
     """``src/sample.py:55-145``.  Returns a block operator v -> A^(-1/2) v on (D,) or (S, D).
     (``key`` / ``num_proj_steps`` select the reference's alternating-projection branch, which it
     disables itself — ``:150`` forces ``key=None`` because the branch returns NaN)"""
-    parts = _SamplerParts(state, Z, D, alpha, model_type, full_set_size, clip_min, method)
+    parts = _cached_parts(state, Z, D, alpha, model_type, full_set_size, clip_min, method)
     eng = parts.eng
     op = BlockOperator(lambda V: parts.apply(V.to(device=eng.device, dtype=torch.float32).contiguous()),
                        (eng.D,), (eng.D,), eng, "inv_matsqrt_vp")

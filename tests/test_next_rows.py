@@ -1,0 +1,90 @@
+"""SURVEY §8(f) "next" rows N2 (log-marginal-likelihood in alpha, src/train_alpha.py) and N3 (evaluation
+metrics, scale_experiments/evaluate.py): oracle on the CPU, HIP-backed product on the GPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from fixtures import classification_2d_data, classifier_state, sine_data, toyregressor_state  # noqa: F401
+from impl import cpu64, impl  # noqa: F401
+import oracle.evaluate as oev
+import oracle.train_alpha as ota
+
+
+def test_log_marginal_likelihood_oracle_gradient(classification_2d_data, classifier_state):
+    """CPU: the literal slogdet formula and its autograd gradient w.r.t. log alpha (finite-difference check)."""
+    X, _ = classification_2d_data
+    X = X[::25]
+    args = (X, classifier_state, "classifier", 200)
+    v, g = ota.grad_log_alpha(math.log(0.3), *args)
+    vp = float(ota.log_marginal_likelihood(0.3 * math.exp(1e-5), *args))
+    vm = float(ota.log_marginal_likelihood(0.3 * math.exp(-1e-5), *args))
+    assert abs((vp - vm) / 2e-5 - g) <= 1e-5 * max(1.0, abs(g))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["classifier", "regressor"])
+def test_log_marginal_likelihood_hip(model, classification_2d_data, classifier_state, sine_data, toyregressor_state):
+    """GPU: value and d/d(log alpha) of the spectral formula == the oracle's slogdet + autograd; one Adam step of
+    update_alpha == optax.adam's first step (-lr * sign(g)); fit_alpha increases the evidence."""
+    import src.train_alpha as ta
+    if model == "classifier":
+        X, _ = classification_2d_data
+        X, st, N = X[::25], classifier_state, 200
+    else:
+        X, _ = sine_data
+        X, st, N = X[::4], toyregressor_state, 270
+    Xd, std = X.cuda().float(), st.to(device="cuda", dtype=torch.float32)
+    for alpha in (0.05, 1.0, 7.0):
+        v, g = ta.log_marginal_likelihood_and_grad(alpha, Xd, std, model, N)
+        vo, go = ota.grad_log_alpha(math.log(alpha), X, st, model, N)
+        assert abs(v - vo) <= 2e-4 * max(1.0, abs(vo)), (alpha, v, vo)
+        assert abs(g - go) <= 2e-4 * max(1.0, abs(go)), (alpha, g, go)
+        assert abs(ta.log_marginal_likelihood(alpha, Xd, std, model, N) - v) < 1e-9 * max(1.0, abs(v))
+    opt = ta.Adam(5e-2)
+    la, s1 = ta.update_alpha(math.log(1.0), opt.init(), opt, Xd, std, model, N)
+    _, go = ota.grad_log_alpha(0.0, X, st, model, N)
+    assert abs(la - 5e-2 * math.copysign(1.0, go)) < 1e-6 and s1["count"] == 1
+    a_fit, hist = ta.fit_alpha(Xd, std, model, N, alpha0=1.0, alpha_lr=5e-2, steps=100)
+    assert hist[-1][1] >= hist[0][1] - 1e-9
+
+
+def test_metric_helpers(impl):
+    """brier / ece / MC-NLL arithmetic == the numpy restatement of evaluate.py:40-63,127-151; AUROC == sklearn."""
+    import lip_amd.evaluate as ev
+    g = np.random.default_rng(0)
+    logits = g.normal(size=(7, 40, 5)) * 2
+    y = g.integers(0, 5, size=40)
+    nll_o, acc_o, probs_o = oev.mc_nll(logits, y)
+    lt, yt = torch.from_numpy(logits), torch.from_numpy(y)
+    lp = torch.log_softmax(lt, -1)
+    lpt = torch.gather(lp, -1, yt[None, :, None].expand(7, -1, 1)).squeeze(-1)
+    nll = -(torch.logsumexp(lpt, 0) - math.log(7)).mean()
+    assert abs(float(nll) - nll_o) < 1e-12
+    probs = torch.softmax(lt, -1).mean(0)
+    assert abs(ev.brier_score(probs, yt) - oev.brier_score(probs_o, y)) < 1e-12
+    assert abs(ev.ece(probs, yt) - oev.ece(probs_o, y)) < 1e-12
+    from sklearn.metrics import roc_auc_score
+    lab = g.integers(0, 2, size=300)
+    sc = np.round(g.normal(size=300) + lab, 1)          # ties on purpose
+    assert abs(ev.roc_auc(torch.from_numpy(lab), torch.from_numpy(sc)) - roc_auc_score(lab, sc)) < 1e-12
+
+
+@pytest.mark.gpu
+def test_eval_dataset_on_blobs(classification_2d_data, classifier_state):
+    """End-to-end harness on the 2-D blobs: eval_dataset_extended / auroc_ood run on the HIP engine, return sane
+    numbers, and the scalable (sampled) NLL agrees with the dense predictive within MC error."""
+    import src.evaluate as ev
+    X, y = classification_2d_data
+    st = classifier_state.to(device="cuda", dtype=torch.float32)
+    Z = X[::8].cuda().float()
+    test = [(X[i:i + 50].cuda().float(), y[i:i + 50].cuda()) for i in range(0, 200, 50)]
+    nll, acc, bri, cal, probs, labels = ev.eval_dataset_extended(st, test, Z, 0.5, 200, "classifier", 400, rng=7)
+    assert probs.shape == (200, 2) and torch.allclose(probs.sum(1), torch.ones(200, device=probs.device), atol=1e-5)
+    assert math.isfinite(nll) and 0.0 <= acc <= 1.0 and 0.0 <= bri <= 2.0 and 0.0 <= cal <= 1.0
+    nll_d, acc_d = ev.eval_dataset(st, test, Z, 0.5, 200, "classifier", 400, rng=7, scalable=False)
+    assert abs(nll - nll_d) < 0.05 and abs(acc - acc_d) < 0.05
+    ood = [(torch.randn(50, 2).cuda() * 6.0, torch.zeros(50))]
+    au = ev.auroc_ood(st, probs, ood, Z, 0.5, 200, "classifier", 200, rng=11)
+    assert 0.0 <= au <= 1.0
