@@ -145,15 +145,17 @@ int lip_vjp(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_m
 int lip_bdot(const float* X, const float* Y, float* out /*[P], overwritten*/, int32_t P, int64_t N, void* stream);
 int lip_axpby(float* Y, const float* X, const float* a /*[P] or NULL*/, float a_s, const float* b /*[P] or NULL*/,
               float b_s, int32_t P, int64_t N, void* stream);      /* Y[p] = (a_s*a[p]) X[p] + (b_s*b[p]) Y[p] */
-/* c[p][j] = <Q[p][j], w[p]>, j < k.   Q is (P, kmax, N).                                 */
+/* Lanczos basis Q is (P, kmax, ldq): row stride ldq >= N with ldq % 4 == 0 and a 16-byte aligned base, so the
+ * basis — (j+1) x the traffic of w — streams with aligned 16-byte loads; w stays (P, N).
+ * c[p][j] = <Q[p][j], w[p]>, j < k.                                                       */
 int lip_multi_dot(const float* Q, const float* w, float* c /*[P][kmax], first k overwritten*/, int32_t P,
-                  int32_t k, int32_t kmax, int64_t N, void* stream);
+                  int32_t k, int32_t kmax, int64_t N, int64_t ldq, void* stream);
 /* w[p] -= sum_j c[p][j] Q[p][j];  nrm2[p] = ||w[p]||^2 after the update.                 */
 int lip_multi_axpy_norm(const float* Q, const float* c, float* w, float* nrm2 /*[P], overwritten*/, int32_t P,
-                        int32_t k, int32_t kmax, int64_t N, void* stream);
-/* Q[p][j] = w[p] * rsqrt(nrm2[p])   (next Lanczos vector)                                */
+                        int32_t k, int32_t kmax, int64_t N, int64_t ldq, void* stream);
+/* Q[p][j] = w[p] * rsqrt(nrm2[p])   (next Lanczos vector; the row padding is zeroed)     */
 int lip_scale_store(const float* w, const float* nrm2, float* Q, int32_t j, int32_t P, int32_t kmax, int64_t N,
-                    void* stream);
+                    int64_t ldq, void* stream);
 /* fused CG update (one pass): x += a p; r -= a Ap; rr[p] = <r,r>, a[p] = rr_old[p]/pAp[p]; inactive probes
  * (active[p]==0) are left untouched.                                                     */
 int lip_cg_update(float* x, float* r, const float* p, const float* Ap, const float* rr_old, const float* pAp,

@@ -67,9 +67,9 @@ SIGNATURES = {
     "lip_vjp": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_float, _V]),
     "lip_bdot": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int64, _V]),
     "lip_axpby": (C.c_int, [_V, _V, _V, C.c_float, _V, C.c_float, C.c_int32, C.c_int64, _V]),
-    "lip_multi_dot": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _V]),
-    "lip_multi_axpy_norm": (C.c_int, [_V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _V]),
-    "lip_scale_store": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _V]),
+    "lip_multi_dot": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _V]),
+    "lip_multi_axpy_norm": (C.c_int, [_V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _V]),
+    "lip_scale_store": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _V]),
     "lip_cg_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int64, _V]),
     "lip_cg_direction": (C.c_int, [_V, _V, _V, _V, _V, C.c_int32, C.c_int64, _V]),
     "lip_fill_rademacher": (C.c_int, [_V, C.c_int32, C.c_int64, C.c_uint64, _V]),

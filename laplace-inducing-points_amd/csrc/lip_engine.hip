@@ -269,7 +269,7 @@ int ready(const lip_engine* e, const char* who) {
 
 extern "C" {
 
-int lip_abi_version(void) { return 1; }
+int lip_abi_version(void) { return 2; }
 const char* lip_last_error(void) { return g_err; }
 int lip_sizeof_op(void) { return (int)sizeof(lip_op_t); }
 

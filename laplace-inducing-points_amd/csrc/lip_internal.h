@@ -53,6 +53,7 @@ struct IgemmP {
   const float* xhat2;
   int blocks_per_cu, stagger;           // first-round stagger (speed only)
   const float* zeros;                   // >= 16 floats of device zeros (masked gather rows)
+  int xcd_remap;                        // XCD-aware tile order (speed only)
 };
 
 struct WgradP {

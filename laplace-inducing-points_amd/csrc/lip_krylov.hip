@@ -86,32 +86,47 @@ __global__ __launch_bounds__(KT) void axpby_kernel(float* Y, const float* X, con
             [&](long long o) { y[o] = ca * x[o] + (useb ? cb * y[o] : 0.f); });
 }
 
-// ---- c[p][j] = <Q[p][j], w[p]>, j < k : each block keeps its chunk of w in registers and streams Q ----
+// ---- Lanczos basis kernels.  Q is (P, kmax, ldq) with ldq % 4 == 0 and a 16-byte aligned base: the rows of
+// the basis — (j+1) x the traffic of w — are read with aligned float4 loads; w (P, N), whose rows inherit the
+// caller's odd alignment, is read / written with coalesced dwords.  Each block keeps its 2048-element chunk of
+// w in registers and streams the k rows of Q past it.
+__device__ __forceinline__ float4 ld_q4(const float* q, long long o, long long N) {
+  float4 v = LD4(q, o);
+  if (o + 3 >= N) {                      // last, partial quad of the row: mask the padding
+    if (o + 1 >= N) v.y = 0.f;
+    if (o + 2 >= N) v.z = 0.f;
+    v.w = 0.f;
+  }
+  return v;
+}
+
+// c[p][j] = <Q[p][j], w[p]>, j < k
 __global__ __launch_bounds__(KT) void multi_dot_kernel(const float* Q, const float* W, float* c, int k, int kmax,
-                                                       long long N) {
+                                                       long long N, long long ldq) {
   extern __shared__ float cs[];   // [k]
   const int p = blockIdx.y;
   const float* w = W + (long long)p * N;
-  const float* q0 = Q + (long long)p * kmax * N;
+  const float* q0 = Q + (long long)p * kmax * ldq;
   for (int j = threadIdx.x; j < k; j += KT) cs[j] = 0.f;
   __syncthreads();
   const long long beg = (long long)blockIdx.x * CHUNK;
-  const long long end = beg + CHUNK < N ? beg + CHUNK : N;
-  // element ownership inside the chunk: thread t owns beg + t + i*KT (coalesced dwords; row bases of
-  // different j share the row's misalignment, so dword accesses keep this kernel simple and exact)
   float wr[8];
+  long long o4[2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const long long o = beg + threadIdx.x + (long long)i * KT;
-    wr[i] = o < end ? w[o] : 0.f;
+  for (int i = 0; i < 2; ++i) {
+    o4[i] = beg + 4ll * (threadIdx.x + i * KT);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[4 * i + e] = (o4[i] + e < N) ? w[o4[i] + e] : 0.f;
   }
   for (int j = 0; j < k; ++j) {
-    const float* q = q0 + (long long)j * N;
+    const float* q = q0 + (long long)j * ldq;
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long long o = beg + threadIdx.x + (long long)i * KT;
-      if (o < end) acc += q[o] * wr[i];
+    for (int i = 0; i < 2; ++i) {
+      if (o4[i] < N) {
+        const float4 v = ld_q4(q, o4[i], N);
+        acc += v.x * wr[4 * i] + v.y * wr[4 * i + 1] + v.z * wr[4 * i + 2] + v.w * wr[4 * i + 3];
+      }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(&cs[j], acc);
@@ -120,51 +135,61 @@ __global__ __launch_bounds__(KT) void multi_dot_kernel(const float* Q, const flo
   for (int j = threadIdx.x; j < k; j += KT) atomicAdd(c + (long long)p * kmax + j, cs[j]);
 }
 
-// ---- w[p] -= sum_j c[p][j] Q[p][j] ; nrm2[p] = ||w[p]||^2 ------------------------------------------------
+// w[p] -= sum_j c[p][j] Q[p][j] ; nrm2[p] = ||w[p]||^2
 __global__ __launch_bounds__(KT) void multi_axpy_norm_kernel(const float* Q, const float* c, float* W, float* nrm2,
-                                                             int k, int kmax, long long N) {
+                                                             int k, int kmax, long long N, long long ldq) {
   extern __shared__ float cs[];   // [k]
   __shared__ float sm[KT / 64];
   const int p = blockIdx.y;
   float* w = W + (long long)p * N;
-  const float* q0 = Q + (long long)p * kmax * N;
+  const float* q0 = Q + (long long)p * kmax * ldq;
   for (int j = threadIdx.x; j < k; j += KT) cs[j] = c[(long long)p * kmax + j];
   __syncthreads();
   const long long beg = (long long)blockIdx.x * CHUNK;
-  const long long end = beg + CHUNK < N ? beg + CHUNK : N;
   float wr[8];
+  long long o4[2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const long long o = beg + threadIdx.x + (long long)i * KT;
-    wr[i] = o < end ? w[o] : 0.f;
+  for (int i = 0; i < 2; ++i) {
+    o4[i] = beg + 4ll * (threadIdx.x + i * KT);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[4 * i + e] = (o4[i] + e < N) ? w[o4[i] + e] : 0.f;
   }
   for (int j = 0; j < k; ++j) {
-    const float* q = q0 + (long long)j * N;
+    const float* q = q0 + (long long)j * ldq;
     const float cj = cs[j];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long long o = beg + threadIdx.x + (long long)i * KT;
-      if (o < end) wr[i] -= cj * q[o];
+    for (int i = 0; i < 2; ++i) {
+      if (o4[i] < N) {
+        const float4 v = ld_q4(q, o4[i], N);
+        wr[4 * i] -= cj * v.x; wr[4 * i + 1] -= cj * v.y; wr[4 * i + 2] -= cj * v.z; wr[4 * i + 3] -= cj * v.w;
+      }
     }
   }
   float acc = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const long long o = beg + threadIdx.x + (long long)i * KT;
-    if (o < end) { w[o] = wr[i]; acc += wr[i] * wr[i]; }
-  }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (o4[i] + e < N) { w[o4[i] + e] = wr[4 * i + e]; acc += wr[4 * i + e] * wr[4 * i + e]; }
   const float t = block_sum(acc, sm);
   if (threadIdx.x == 0) atomicAdd(nrm2 + p, t);
 }
 
-// ---- Q[p][j] = w[p] / sqrt(nrm2[p]) ----------------------------------------------------------------------
+// Q[p][j] = w[p] / sqrt(nrm2[p])   (padding of the row is zeroed)
 __global__ __launch_bounds__(KT) void scale_store_kernel(const float* W, const float* nrm2, float* Q, int j, int kmax,
-                                                         long long N) {
+                                                         long long N, long long ldq) {
   const int p = blockIdx.y;
   const float inv = rsqrtf(nrm2[p]);
   const float* w = W + (long long)p * N;
-  float* q = Q + ((long long)p * kmax + j) * N;
-  for (long long o = (long long)blockIdx.x * KT + threadIdx.x; o < N; o += (long long)gridDim.x * KT) q[o] = w[o] * inv;
+  float* q = Q + ((long long)p * kmax + j) * ldq;
+  for (long long o = 4ll * ((long long)blockIdx.x * KT + threadIdx.x); o < ldq; o += 4ll * (long long)gridDim.x * KT) {
+    float4 v;
+    v.x = (o < N) ? w[o] * inv : 0.f;
+    v.y = (o + 1 < N) ? w[o + 1] * inv : 0.f;
+    v.z = (o + 2 < N) ? w[o + 2] * inv : 0.f;
+    v.w = (o + 3 < N) ? w[o + 3] * inv : 0.f;
+    ST4(q, o, v);
+  }
 }
 
 // ---- fused CG update: a = rr_old/pAp ; x += a p ; r -= a Ap ; rr_new = <r, r> ------------------------------
@@ -309,32 +334,44 @@ int lip_axpby(float* Y, const float* X, const float* a, float a_s, const float* 
   return LIP_OK;
 }
 
-int lip_multi_dot(const float* Q, const float* w, float* c, int32_t P, int32_t k, int32_t kmax, int64_t N, void* stream) {
+static int check_basis(const float* Q, int64_t N, int64_t ldq, const char* who) {
+  if (ldq < N || (ldq & 3) || (((unsigned long long)Q) & 15ull)) {
+    set_error("%s: the basis needs ldq >= N, ldq %% 4 == 0 and a 16-byte aligned base", who);
+    return LIP_ERR_ARG;
+  }
+  return LIP_OK;
+}
+
+int lip_multi_dot(const float* Q, const float* w, float* c, int32_t P, int32_t k, int32_t kmax, int64_t N, int64_t ldq,
+                  void* stream) {
   if (!Q || !w || !c || P <= 0 || k <= 0 || k > kmax || N <= 0 || k > 8192) { set_error("lip_multi_dot: bad argument"); return LIP_ERR_ARG; }
+  if (check_basis(Q, N, ldq, "lip_multi_dot")) return LIP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   LIP_CHECK_HIP(hipMemset2DAsync(c, sizeof(float) * kmax, 0, sizeof(float) * k, P, st));
   const unsigned nb = (unsigned)((N + CHUNK - 1) / CHUNK);
-  hipLaunchKernelGGL(multi_dot_kernel, dim3(nb, P), dim3(KT), sizeof(float) * k, st, Q, w, c, k, kmax, (long long)N);
+  hipLaunchKernelGGL(multi_dot_kernel, dim3(nb, P), dim3(KT), sizeof(float) * k, st, Q, w, c, k, kmax, (long long)N, (long long)ldq);
   LIP_CHECK_HIP(hipGetLastError());
   return LIP_OK;
 }
 
 int lip_multi_axpy_norm(const float* Q, const float* c, float* w, float* nrm2, int32_t P, int32_t k, int32_t kmax,
-                        int64_t N, void* stream) {
+                        int64_t N, int64_t ldq, void* stream) {
   if (!Q || !w || !c || !nrm2 || P <= 0 || k <= 0 || k > kmax || N <= 0 || k > 8192) { set_error("lip_multi_axpy_norm: bad argument"); return LIP_ERR_ARG; }
+  if (check_basis(Q, N, ldq, "lip_multi_axpy_norm")) return LIP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   LIP_CHECK_HIP(hipMemsetAsync(nrm2, 0, sizeof(float) * P, st));
   const unsigned nb = (unsigned)((N + CHUNK - 1) / CHUNK);
-  hipLaunchKernelGGL(multi_axpy_norm_kernel, dim3(nb, P), dim3(KT), sizeof(float) * k, st, Q, c, w, nrm2, k, kmax, (long long)N);
+  hipLaunchKernelGGL(multi_axpy_norm_kernel, dim3(nb, P), dim3(KT), sizeof(float) * k, st, Q, c, w, nrm2, k, kmax, (long long)N, (long long)ldq);
   LIP_CHECK_HIP(hipGetLastError());
   return LIP_OK;
 }
 
 int lip_scale_store(const float* w, const float* nrm2, float* Q, int32_t j, int32_t P, int32_t kmax, int64_t N,
-                    void* stream) {
+                    int64_t ldq, void* stream) {
   if (!Q || !w || !nrm2 || P <= 0 || j < 0 || j >= kmax || N <= 0) { set_error("lip_scale_store: bad argument"); return LIP_ERR_ARG; }
+  if (check_basis(Q, N, ldq, "lip_scale_store")) return LIP_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(scale_store_kernel, dim3(nblk_for(N, CHUNK, 2048), P), dim3(KT), 0, st, w, nrm2, Q, j, kmax, (long long)N);
+  hipLaunchKernelGGL(scale_store_kernel, dim3(nblk_for(N, CHUNK * 2, 2048), P), dim3(KT), 0, st, w, nrm2, Q, j, kmax, (long long)N, (long long)ldq);
   LIP_CHECK_HIP(hipGetLastError());
   return LIP_OK;
 }

@@ -422,7 +422,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   const int wm = wave / WN, wn = wave % WN;
   const int N = prm.N, R = prm.R;
   const int tiles_n = (N + BN - 1) / BN;
-  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  // XCD-aware tile order (speed only): blocks b and b + 8 share an XCD under round-robin dispatch, so XCD x
+  // gets the contiguous tile range [x*q + min(x, r), ...) (bijective for any tile count): neighbouring row
+  // tiles share their conv halo rows through one L2 instead of fetching them into eight.
+  int bid = blockIdx.x;
+  if (prm.xcd_remap) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
   const int p = blockIdx.y;
   const int r0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -943,6 +951,8 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
     if (!q.zeros) return hipErrorOutOfMemory;
     q.blocks_per_cu = bpc;
     q.stagger = stagger_enabled();
+    static const int xcd = getenv("LIP_XCD") ? atoi(getenv("LIP_XCD")) : 0;   // measured r24: no gain -> off
+    q.xcd_remap = xcd;
     if (abl == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), 0, st, q);
     else if (abl == 2) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 2>), grid, dim3(T::NT), 0, st, q);
     else if (abl == 3) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 3>), grid, dim3(T::NT), 0, st, q);

@@ -69,22 +69,24 @@ def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Te
         raise ValueError(f"num_matvecs={k} exceeds dimension {N}")
     st = nv.stream_ptr()
     dev = V0.device
-    Q = torch.empty(P, k, N, device=dev, dtype=torch.float32)
+    ldq = (N + 3) // 4 * 4                     # padded row stride: aligned float4 streaming of the basis
+    Qbuf = torch.empty(P, k, ldq, device=dev, dtype=torch.float32)
+    Q = Qbuf[:, :, :N]
     diag = torch.zeros(P, k, device=dev, dtype=torch.float32)
     off = torch.zeros(P, max(k - 1, 0), device=dev, dtype=torch.float32)
     c1 = torch.empty(P, k, device=dev, dtype=torch.float32)
     c2 = torch.empty(P, k, device=dev, dtype=torch.float32)
     nrm2 = bdot(V0, V0)
-    nv.check(lib.lip_scale_store(nv.ptr(V0), nv.ptr(nrm2), nv.ptr(Q), 0, P, k, N, st), "lip_scale_store")
+    nv.check(lib.lip_scale_store(nv.ptr(V0), nv.ptr(nrm2), nv.ptr(Qbuf), 0, P, k, N, ldq, st), "lip_scale_store")
     alive = torch.ones(P, device=dev, dtype=torch.bool)
     for j in range(k):
-        w = matvec(Q[:, j].contiguous()).contiguous()
+        w = matvec(Q[:, j].contiguous()).contiguous()      # (P, N) copy of basis row j (N may be < ldq)
         _chk(w)
         wn2 = bdot(w, w)
-        nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c1), P, j + 1, k, N, st), "lip_multi_dot")
-        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c1), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, st), "lip_multi_axpy_norm")
-        nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c2), P, j + 1, k, N, st), "lip_multi_dot")
-        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c2), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, st), "lip_multi_axpy_norm")
+        nv.check(lib.lip_multi_dot(nv.ptr(Qbuf), nv.ptr(w), nv.ptr(c1), P, j + 1, k, N, ldq, st), "lip_multi_dot")
+        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Qbuf), nv.ptr(c1), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, ldq, st), "lip_multi_axpy_norm")
+        nv.check(lib.lip_multi_dot(nv.ptr(Qbuf), nv.ptr(w), nv.ptr(c2), P, j + 1, k, N, ldq, st), "lip_multi_dot")
+        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Qbuf), nv.ptr(c2), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, ldq, st), "lip_multi_axpy_norm")
         # breakdown guard: once the Krylov space of a probe is exhausted (residual at rounding level)
         # the remaining basis vectors are zero and the tridiagonal block decouples (diag 1, offdiag 0),
         # which leaves f(T) e1 unchanged instead of producing 0/0.
@@ -93,7 +95,8 @@ def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Te
             alive = alive & (nrm2 > (1e-10 * wn2).clamp_min(1e-36))
             off[:, j] = torch.where(alive, torch.sqrt(nrm2), torch.zeros_like(nrm2))
             safe = torch.where(alive, nrm2, torch.full_like(nrm2, float("inf")))
-            nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(safe), nv.ptr(Q), j + 1, P, k, N, st), "lip_scale_store")
+            nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(safe), nv.ptr(Qbuf), j + 1, P, k, N, ldq, st), "lip_scale_store")
+    Q.basis_buffer, Q.ldq = Qbuf, ldq      # the padded storage the HIP kernels take
     return Q, diag, off
 
 
@@ -133,8 +136,8 @@ def funm_lanczos_sym(dense_funm: Callable, num_matvecs: int):
         coef = (-(fT[:, :, 0] * length.double()[:, None])).float().contiguous()      # (P, k)
         out = torch.zeros(P, N, device=B.device, dtype=torch.float32)
         nrm = torch.empty(P, device=B.device, dtype=torch.float32)
-        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(coef), nv.ptr(out), nv.ptr(nrm), P, k, k, N, nv.stream_ptr()),
-                 "lip_multi_axpy_norm")
+        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q.basis_buffer), nv.ptr(coef), nv.ptr(out), nv.ptr(nrm), P, k, k, N, Q.ldq,
+                                         nv.stream_ptr()), "lip_multi_axpy_norm")
         return out
 
     return estimate

@@ -36,22 +36,26 @@ def test_bdot_axpby(P, N):
 @pytest.mark.parametrize("P,k,kmax,N", [(2, 1, 4, 500), (3, 7, 9, 4099), (2, 33, 40, 70001)])
 def test_lanczos_primitives(P, k, kmax, N):
     lib = nv.load()
-    Q = _blk(P * kmax, N, 3).reshape(P, kmax, N).contiguous()
+    ldq = (N + 3) // 4 * 4
+    Qbuf = torch.full((P, kmax, ldq), float("nan"), device="cuda")        # NaN padding must never leak
+    Qbuf[:, :, :N] = _blk(P * kmax, N, 3).reshape(P, kmax, N)
+    Q = Qbuf[:, :, :N]
     w = _blk(P, N, 4)
     c = torch.full((P, kmax), 7.0, device="cuda")
-    nv.check(lib.lip_multi_dot(nv.ptr(Q), nv.ptr(w), nv.ptr(c), P, k, kmax, N, nv.stream_ptr()), "multi_dot")
+    nv.check(lib.lip_multi_dot(nv.ptr(Qbuf), nv.ptr(w), nv.ptr(c), P, k, kmax, N, ldq, nv.stream_ptr()), "multi_dot")
     ref = torch.einsum("pkn,pn->pk", Q[:, :k].double(), w.double())
     assert torch.allclose(c[:, :k].double(), ref, rtol=1e-4, atol=1e-2)
     assert torch.all(c[:, k:] == 7.0)
     w2 = w.clone()
     nrm = torch.empty(P, device="cuda")
-    nv.check(lib.lip_multi_axpy_norm(nv.ptr(Q), nv.ptr(c), nv.ptr(w2), nv.ptr(nrm), P, k, kmax, N, nv.stream_ptr()), "maxpy")
+    nv.check(lib.lip_multi_axpy_norm(nv.ptr(Qbuf), nv.ptr(c), nv.ptr(w2), nv.ptr(nrm), P, k, kmax, N, ldq, nv.stream_ptr()), "maxpy")
     refw = w.double() - torch.einsum("pk,pkn->pn", c[:, :k].double(), Q[:, :k].double())
     assert torch.allclose(w2.double(), refw, rtol=1e-4, atol=1e-2 * refw.abs().max().item() * 1e-2)
     assert torch.allclose(nrm.double(), (w2.double() ** 2).sum(1), rtol=1e-4)
     j = k - 1
-    nv.check(lib.lip_scale_store(nv.ptr(w2), nv.ptr(nrm), nv.ptr(Q), j, P, kmax, N, nv.stream_ptr()), "scale_store")
+    nv.check(lib.lip_scale_store(nv.ptr(w2), nv.ptr(nrm), nv.ptr(Qbuf), j, P, kmax, N, ldq, nv.stream_ptr()), "scale_store")
     assert torch.allclose(Q[:, j], w2 / nrm.sqrt()[:, None], rtol=1e-5, atol=1e-6)
+    assert torch.all(Qbuf[:, j, N:] == 0)
 
 
 @pytest.mark.parametrize("P,N", [(3, 1027), (2, 250001)])
