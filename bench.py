@@ -209,6 +209,21 @@ def main():
                                 "(the matrix-free kernel is), reported because it is what an inducing-point user "
                                 "should call")
 
+    # ---- Krylov / trace primitives: HBM roofline (algorithmic bytes / time, peak 8 TB/s spec) ------------------
+    krylov_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import krylov_bench
+        del eng.work                                   # release the 6.7 GB probe workspace first
+        torch.cuda.empty_cache()
+        kb = krylov_bench.run(D=1084586, P=256, k=36)
+        krylov_line = dict(bound="hbm", peak=8000.0, unit="GB/s",
+                           cg_step=kb["cg_step"]["GBps"], lanczos_step_j35=kb["lanczos_step_cgs2"]["j=35"]["GBps"],
+                           hutchinson_dot=kb["bdot"]["GBps"], axpby=kb["axpby"]["GBps"],
+                           fill_rademacher=kb["fill_rademacher"]["GBps"],
+                           frac_cg_step=kb["cg_step"]["GBps"] / 8000.0,
+                           bytes_model="CG step 44*D B, Lanczos step j with CGS2 4*D*(4*(j+2)+4) B, dot 8*D B per probe")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(net, n)
@@ -222,7 +237,7 @@ def main():
                                          "full_set_size=49000; data sum sharded over ranks, one all-reduce per matvec",
                                 examples_per_gpu=n, probes=P, D=eng.D, probe_chunk=eng.chunk,
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:
