@@ -61,7 +61,11 @@ enum {
   LIP_OP_POOL_BWD = 5,    /* broadcast/HW, times dphi, plus parameter reductions                         */
   LIP_OP_PRIMAL_POST = 6, /* z -> xhat, y, a = act(y), dphi = act'(y)   (primal pass, once per binding)  */
   LIP_OP_SOFTMAX = 7,     /* logits -> p, sqrt(p)                        (primal pass)                   */
-  LIP_OP_HEAD = 8         /* output-space Hessian / square-root factor action  src/ggn.py:16-39,125-131  */
+  LIP_OP_HEAD = 8,        /* output-space Hessian / square-root factor action  src/ggn.py:16-39,125-131  */
+  LIP_OP_MAXPOOL_PRIMAL = 9,  /* max pool of the primal activations + cached argmax (aux0)             */
+  LIP_OP_MAXPOOL_FWD = 10,    /* tangent of max pool: gather at the cached argmax                      */
+  LIP_OP_MAXPOOL_BWD = 11     /* cotangent of max pool (gather over the covering windows), times dphi,
+                                 plus parameter reductions — same epilogue fields as LIP_OP_POOL_BWD   */
 };
 
 /* head modes */

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblip_hip.so")
 LIP_OK = 0
 SP_NONE, SP_THETA, SP_CONST, SP_PRIM, SP_WORK, SP_VIN, SP_YOUT, SP_HEAD = -1, 0, 1, 2, 3, 4, 5, 6
 OP_IGEMM, OP_WGRAD, OP_REDUCE, OP_POOL_FWD, OP_POOL_BWD, OP_PRIMAL_POST, OP_SOFTMAX, OP_HEAD = 1, 2, 3, 4, 5, 6, 7, 8
+OP_MAXPOOL_PRIMAL, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD = 9, 10, 11
 HEAD_GGN, HEAD_LT, HEAD_L, HEAD_OUT, HEAD_IN = 0, 1, 2, 3, 4
 TAPE_PRIMAL, TAPE_TANGENT, TAPE_BACKWARD = 0, 1, 2
 

@@ -181,6 +181,27 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       else RUN_CHECK(launch_pool_bwd(p, c.P, c.st), "pool_bwd launch");
       return LIP_OK;
     }
+    case LIP_OP_MAXPOOL_PRIMAL:
+    case LIP_OP_MAXPOOL_FWD:
+    case LIP_OP_MAXPOOL_BWD: {
+      const lip_seg_t& g = op.seg[0];
+      MaxPoolP p;
+      memset(&p, 0, sizeof(p));
+      p.in = resolve(c, g.a); p.in_ps = g.a.pstride;
+      p.out = resolve(c, op.out); p.out_ps = op.out.pstride;
+      p.amax_w = resolve(c, op.aux0); p.amax = p.amax_w;
+      p.n = op.n_img; p.IH = g.IH; p.IW = g.IW; p.OH = op.OH; p.OW = op.OW; p.C = op.N;
+      p.KH = g.KH; p.KW = g.KW; p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
+      p.dphi = resolve(c, op.dphi);
+      p.xhat = resolve(c, op.xhat2);
+      p.red0 = resolve(c, op.red0); p.red0_ps = op.red0.pstride;
+      p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
+      if (!p.in || !p.out || !p.amax || p.C <= 0 || p.C > 8192 || p.stride <= 0 || (p.red1 && !p.xhat)) { set_error("MAXPOOL: bad operands"); return LIP_ERR_ARG; }
+      if (op.kind == LIP_OP_MAXPOOL_PRIMAL) RUN_CHECK(launch_maxpool_primal(p, c.st), "maxpool_primal launch");
+      else if (op.kind == LIP_OP_MAXPOOL_FWD) RUN_CHECK(launch_maxpool_fwd(p, c.P, c.st), "maxpool_fwd launch");
+      else RUN_CHECK(launch_maxpool_bwd(p, c.P, c.st), "maxpool_bwd launch");
+      return LIP_OK;
+    }
     case LIP_OP_PRIMAL_POST: {
       PrimalPostP p;
       memset(&p, 0, sizeof(p));

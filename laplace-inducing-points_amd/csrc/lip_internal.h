@@ -86,6 +86,16 @@ struct PoolP {
   float* red1; long long red1_ps;
 };
 
+struct MaxPoolP {
+  const float* in; long long in_ps;     // [P][n][IH][IW][C]   (bwd: cotangent of the pooled tensor [P][n][OH][OW][C])
+  float* out; long long out_ps;         // [P][n][OH][OW][C]   (bwd: [P][n][IH][IW][C])
+  float* amax_w; const float* amax;     // [n][OH][OW][C] argmax as linear pixel index ih*IW+iw (float)
+  int n, IH, IW, OH, OW, C, KH, KW, stride, pad_h, pad_w;
+  const float* dphi; const float* xhat;
+  float* red0; long long red0_ps;
+  float* red1; long long red1_ps;
+};
+
 struct PrimalPostP {
   const float* z; float* a; float* dphi; float* xhat;   // all [R][N]
   const float* bias;                    // [N] or null          (THETA)
@@ -109,6 +119,9 @@ hipError_t launch_reduce(const ReduceP& p, int P, hipStream_t st);
 hipError_t launch_pool_fwd(const PoolP& p, int P, hipStream_t st);
 hipError_t launch_pool_bwd(const PoolP& p, int P, hipStream_t st);
 hipError_t launch_primal_post(const PrimalPostP& p, hipStream_t st);
+hipError_t launch_maxpool_primal(const MaxPoolP& p, hipStream_t st);
+hipError_t launch_maxpool_fwd(const MaxPoolP& p, int P, hipStream_t st);
+hipError_t launch_maxpool_bwd(const MaxPoolP& p, int P, hipStream_t st);
 hipError_t launch_softmax(const float* logits, float* prob, float* sqrtp, int n, int K, hipStream_t st);
 hipError_t launch_head(const HeadP& p, int P, hipStream_t st);
 hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st);

@@ -118,6 +118,122 @@ hipError_t launch_pool_bwd(const PoolP& p, int P, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---- max pool --------------------------------------------------------------------------------------------------
+// primal: out = max over the window, argmax cached as the linear pixel index of the winning input (first max wins)
+__global__ __launch_bounds__(256) void maxpool_primal_kernel(const MaxPoolP prm) {
+  const long long total = (long long)prm.n * prm.OH * prm.OW * prm.C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % prm.C);
+    long long t = idx / prm.C;
+    const int ow = (int)(t % prm.OW); t /= prm.OW;
+    const int oh = (int)(t % prm.OH);
+    const int i = (int)(t / prm.OH);
+    float best = -3.0e38f; int bi = -1;
+    for (int kh = 0; kh < prm.KH; ++kh) {
+      const int ih = oh * prm.stride + kh - prm.pad_h;
+      if (ih < 0 || ih >= prm.IH) continue;
+      for (int kw = 0; kw < prm.KW; ++kw) {
+        const int iw = ow * prm.stride + kw - prm.pad_w;
+        if (iw < 0 || iw >= prm.IW) continue;
+        const float v = prm.in[(((long long)i * prm.IH + ih) * prm.IW + iw) * prm.C + c];
+        if (v > best) { best = v; bi = ih * prm.IW + iw; }
+      }
+    }
+    prm.out[idx] = best;
+    prm.amax_w[idx] = (float)bi;
+  }
+}
+
+hipError_t launch_maxpool_primal(const MaxPoolP& p, hipStream_t st) {
+  const long long total = (long long)p.n * p.OH * p.OW * p.C;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(maxpool_primal_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// tangent: out[p][i][oh][ow][c] = in[p][i][argmax][c]
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const MaxPoolP prm) {
+  const int p = blockIdx.y;
+  const long long per_img_out = (long long)prm.OH * prm.OW * prm.C, per_img_in = (long long)prm.IH * prm.IW * prm.C;
+  const long long total = prm.n * per_img_out;
+  const float* in = prm.in + (long long)p * prm.in_ps;
+  float* out = prm.out + (long long)p * prm.out_ps;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % prm.C);
+    const long long i = idx / per_img_out;
+    const int pix = (int)prm.amax[idx];
+    out[idx] = pix >= 0 ? in[i * per_img_in + (long long)pix * prm.C + c] : 0.f;
+  }
+}
+
+hipError_t launch_maxpool_fwd(const MaxPoolP& p, int P, hipStream_t st) {
+  const long long total = (long long)p.n * p.OH * p.OW * p.C;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), P), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// cotangent: out[p][i][ih][iw][c] = dphi * sum over windows (oh, ow) covering (ih, iw) whose argmax is (ih, iw)
+// of in[p][i][oh][ow][c]; plus the reductions of LIP_OP_POOL_BWD.  A gather, so no atomics on the tensor.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const MaxPoolP prm) {
+  extern __shared__ float sm[];           // [2*C]
+  const int C = prm.C, p = blockIdx.y;
+  float* s0 = sm; float* s1 = sm + C;
+  const bool red = prm.red0 || prm.red1;
+  if (red) {
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+    __syncthreads();
+  }
+  const long long per_img_in = (long long)prm.IH * prm.IW * C, per_img_g = (long long)prm.OH * prm.OW * C;
+  const long long total = prm.n * per_img_in;
+  const float* g = prm.in + (long long)p * prm.in_ps;
+  float* out = prm.out + (long long)p * prm.out_ps;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int iw = (int)(t % prm.IW); t /= prm.IW;
+    const int ih = (int)(t % prm.IH);
+    const long long i = t / prm.IH;
+    const float me = (float)(ih * prm.IW + iw);
+    float v = 0.f;
+    for (int kh = 0; kh < prm.KH; ++kh) {
+      const int th = ih + prm.pad_h - kh;
+      if (th < 0 || (th % prm.stride) != 0) continue;
+      const int oh = th / prm.stride;
+      if (oh >= prm.OH) continue;
+      for (int kw = 0; kw < prm.KW; ++kw) {
+        const int tw = iw + prm.pad_w - kw;
+        if (tw < 0 || (tw % prm.stride) != 0) continue;
+        const int ow = tw / prm.stride;
+        if (ow >= prm.OW) continue;
+        const long long o = i * per_img_g + ((long long)oh * prm.OW + ow) * C + c;
+        if (prm.amax[o] == me) v += g[o];
+      }
+    }
+    if (prm.dphi) v *= prm.dphi[idx];
+    out[idx] = v;
+    if (red) {
+      atomicAdd(&s0[c], v);
+      if (prm.red1) atomicAdd(&s1[c], v * prm.xhat[idx]);
+    }
+  }
+  if (red) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + c, s0[c]);
+      if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + c, s1[c]);
+    }
+  }
+}
+
+hipError_t launch_maxpool_bwd(const MaxPoolP& p, int P, hipStream_t st) {
+  const long long total = (long long)p.n * p.IH * p.IW * p.C;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), P), dim3(256),
+                     2 * p.C * sizeof(float), st, p);
+  return hipGetLastError();
+}
+
 // ---- primal post-processing: z -> (xhat, a = act(y), dphi = act'(y)),  y = BN(z + bias) + res --------
 __device__ __forceinline__ void act_eval(int act, float y, float& a, float& d) {
   if (act == 1) { a = y > 0.f ? y : 0.f; d = y > 0.f ? 1.f : 0.f; }

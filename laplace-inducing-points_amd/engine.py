@@ -101,6 +101,7 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
     a_off: Dict[int, int] = {0: palloc(n * tens[0][0] * tens[0][1] * tens[0][2])}
     dphi_off: Dict[int, int] = {}
     xhat_off: Dict[int, int] = {}
+    amax_off: Dict[int, int] = {}
     producer: Dict[int, Unit] = {}
     zmax = 0
     for u in net.units:
@@ -110,6 +111,8 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
             a_off[u.dst] = a_off[u.src]
             continue
         a_off[u.dst] = palloc(n * h * w * c)
+        if u.kind == "maxpool":
+            amax_off[u.dst] = palloc(n * h * w * c)
         if u.kind == "conv":
             zmax = max(zmax, n * h * w * c)
             if u.act != "none":
@@ -156,6 +159,10 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
         ih, iw, _ = tens[u.src]
         return dict(IH=ih, IW=iw, Cc=u.cin, KH=u.kh, KW=u.kw, stride=u.stride, pad_h=u.pad_h, pad_w=u.pad_w)
 
+    def pool_seg(u: Unit, a_ref):
+        ih, iw, cc = tens[u.src]
+        return _seg(a_ref, NONE, ih, iw, cc, u.kh, u.kw, u.stride, u.pad_h, u.pad_w, 0)
+
     # ------------------------------------------------------------------ primal tape
     primal: List[SymOp] = []
     for u in net.units:
@@ -166,6 +173,10 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
             ih, iw, _ = tens[u.src]
             primal.append(SymOp(nv.OP_POOL_FWD, dict(n_img=n, OH=ih, OW=iw, N=c, fscale=1.0 / (ih * iw)),
                                 dict(out=P(a_off[u.dst])), [dict(a=P(a_off[u.src]), b=NONE)]))
+            continue
+        if u.kind == "maxpool":
+            primal.append(SymOp(nv.OP_MAXPOOL_PRIMAL, dict(n_img=n, OH=oh, OW=ow, N=c),
+                                dict(out=P(a_off[u.dst]), aux0=P(amax_off[u.dst])), [pool_seg(u, P(a_off[u.src]))]))
             continue
         g = geom(u)
         primal.append(SymOp(nv.OP_IGEMM, dict(n_img=n, OH=oh, OW=ow, N=c), dict(out=P(z_off)),
@@ -209,6 +220,11 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
             ih, iw, _ = tens[u.src]
             tangent.append(SymOp(nv.OP_POOL_FWD, dict(n_img=n, OH=ih, OW=iw, N=c, fscale=1.0 / (ih * iw)),
                                  dict(out=W(out)), [dict(a=W(da[u.src]), b=NONE)]))
+            da[u.dst] = out
+            continue
+        if u.kind == "maxpool":
+            tangent.append(SymOp(nv.OP_MAXPOOL_FWD, dict(n_img=n, OH=oh, OW=ow, N=c),
+                                 dict(out=W(out), aux0=P(amax_off[u.dst])), [pool_seg(u, W(da[u.src]))]))
             da[u.dst] = out
             continue
         g = geom(u)
@@ -275,13 +291,24 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
             conv_c = [cu for cu, role in cons if role == "src" and cu.kind == "conv"]
             res_c = [cu for cu, role in cons if role == "res"]
             pool_c = [cu for cu, role in cons if role == "src" and cu.kind == "meanpool"]
+            mpool_c = [cu for cu, role in cons if role == "src" and cu.kind == "maxpool"]
             view_c = [cu for cu, role in cons if cu.kind == "view"]
             if view_c:
                 raise NotImplementedError("flatten of a non-input tensor is not supported by the HIP engine yet")
-            if len(res_c) > 1 or len(conv_c) > 3 or (pool_c and (conv_c or res_c)):
+            if len(res_c) > 1 or len(conv_c) > 3 or ((pool_c or mpool_c) and (conv_c or res_c)) or len(mpool_c) > 1:
                 raise NotImplementedError(f"unsupported fan-out at tensor {t}")
             reds = param_reds(u)
-            if pool_c:
+            if mpool_c:
+                mu = mpool_c[0]
+                moh, mow, _ = tens[mu.dst]
+                out = VT(tsize(t), f"g{t}")
+                refs = dict(out=W(out), aux0=P(amax_off[mu.dst]), **reds)
+                if t in dphi_off:
+                    refs["dphi"] = P(dphi_off[t])
+                backward.append(SymOp(nv.OP_MAXPOOL_BWD, dict(n_img=n, OH=moh, OW=mow, N=c), refs,
+                                      [pool_seg(mu, W(gp[mu.dst]))]))
+                gp[t] = out
+            elif pool_c:
                 pu = pool_c[0]
                 out = VT(tsize(t), f"g{t}")
                 refs = dict(out=W(out), **reds)

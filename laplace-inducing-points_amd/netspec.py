@@ -127,14 +127,8 @@ class NetSpec:
              padding: str = "SAME", bn: Optional[str] = None, res: Optional[int] = None,
              act: str = "none", use_bias: bool = False, scope: Path = ()) -> int:
         h, w, cin = self.tensors[src]
-        if padding == "SAME":
-            oh, ph = _same_pad(h, k, stride)
-            ow, pw = _same_pad(w, k, stride)
-        elif padding == "VALID":
-            oh, ph = (h - k) // stride + 1, 0
-            ow, pw = (w - k) // stride + 1, 0
-        else:
-            raise ValueError(padding)
+        oh, ph = self._out_and_pad(h, k, stride, padding)
+        ow, pw = self._out_and_pad(w, k, stride, padding)
         dst = self._new((oh, ow, features))
         p = self.param_root + tuple(scope) + (name,)
         u = Unit("conv", src, dst, k, k, stride, ph, pw, cin, features,
@@ -148,6 +142,28 @@ class NetSpec:
         if res is not None:
             assert self.tensors[res] == self.tensors[dst], "residual shape mismatch"
         self.units.append(u)
+        self.out = dst
+        return dst
+
+    @staticmethod
+    def _out_and_pad(n_in: int, k: int, stride: int, padding):
+        """(n_out, pad_lo) for 'SAME' (XLA/Flax: odd extra pad on the high side), 'VALID', or an explicit
+        symmetric integer padding (torch convention)."""
+        if padding == "SAME":
+            return _same_pad(n_in, k, stride)
+        if padding == "VALID":
+            return (n_in - k) // stride + 1, 0
+        if isinstance(padding, int):
+            return (n_in + 2 * padding - k) // stride + 1, padding
+        raise ValueError(padding)
+
+    def maxpool(self, src: int, k: int = 3, stride: int = 2, padding="SAME") -> int:
+        """``nn.max_pool`` (window k x k); padded positions never win."""
+        h, w, c = self.tensors[src]
+        oh, ph = self._out_and_pad(h, k, stride, padding)
+        ow, pw = self._out_and_pad(w, k, stride, padding)
+        dst = self._new((oh, ow, c))
+        self.units.append(Unit("maxpool", src, dst, k, k, stride, ph, pw, c, c))
         self.out = dst
         return dst
 
@@ -235,6 +251,14 @@ class NetSpec:
                 continue
             if u.kind == "meanpool":
                 vals[u.dst] = a.mean(dim=(1, 2), keepdim=True)
+                continue
+            if u.kind == "maxpool":
+                oh, ow, _ = self.tensors[u.dst]
+                h, w = a.shape[1], a.shape[2]
+                hi_h = max((oh - 1) * u.stride + u.kh - h - u.pad_h, 0)
+                hi_w = max((ow - 1) * u.stride + u.kw - w - u.pad_w, 0)
+                an = F.pad(a.permute(0, 3, 1, 2), (u.pad_w, hi_w, u.pad_h, hi_h), value=float("-inf"))
+                vals[u.dst] = F.max_pool2d(an, (u.kh, u.kw), stride=u.stride).permute(0, 2, 3, 1)
                 continue
             W = _get(params, u.kernel)
             if u.kh == 1 and u.kw == 1 and u.stride == 1:

@@ -53,6 +53,39 @@ def ResNet1M(num_classes: int, input_shape: Sequence[int] = (32, 32, 3),
     return net
 
 
+def _bottleneck(net: NetSpec, x: int, scope: str, planes: int, stride: int, expansion: int = 4) -> int:
+    """torchvision-style bottleneck: 1x1 -> 3x3 (stride) -> 1x1 (x expansion), BN after each, projection shortcut
+    when the shape changes; symmetric padding 1 on the 3x3 (torch convention)."""
+    sc = (scope,)
+    out_ch = planes * expansion
+    h = net.conv(x, "Conv_0", planes, 1, 1, padding=0, bn="BatchNorm_0", act="relu", scope=sc)
+    h = net.conv(h, "Conv_1", planes, 3, stride, padding=1, bn="BatchNorm_1", act="relu", scope=sc)
+    if stride != 1 or net.tensors[x][2] != out_ch:
+        r = net.conv(x, "Conv_3", out_ch, 1, stride, padding=0, bn="BatchNorm_3", act="none", scope=sc)
+    else:
+        r = x
+    return net.conv(h, "Conv_2", out_ch, 1, 1, padding=0, bn="BatchNorm_2", res=r, act="relu", scope=sc)
+
+
+def ResNet50(num_classes: int = 1000, input_shape: Sequence[int] = (224, 224, 3), stem: int = 64,
+             widths: Sequence[int] = (64, 128, 256, 512), blocks: Sequence[int] = (3, 4, 6, 3)) -> NetSpec:
+    """BASELINE.json configs[4]: the torchvision ResNet-50 architecture defined locally (~25.6 M parameters at the
+    defaults; random init, no download): 7x7/2 stem + BN + ReLU, 3x3/2 max pool, bottleneck stages, global mean
+    pool, Dense.  Not in the reference; smaller ``widths`` / ``blocks`` give parity-test sizes."""
+    net = NetSpec(tuple(input_shape))
+    x = net.conv(0, "Conv_0", stem, 7, 2, padding=3, bn="BatchNorm_0", act="relu")
+    x = net.maxpool(x, 3, 2, padding=1)
+    b = 0
+    for si, (planes, nb) in enumerate(zip(widths, blocks)):
+        for j in range(nb):
+            x = _bottleneck(net, x, f"Bottleneck_{b}", planes, 2 if (si > 0 and j == 0) else 1)
+            b += 1
+    x = net.meanpool(x)
+    net.dense(x, "Dense_0", num_classes)
+    net.model_type = "classifier"
+    return net
+
+
 def get_model(model_cfg) -> NetSpec:
     """Reference ``src/scalemodels.py:166-186`` (LeNet5 is not on the hot-path configs)."""
     name = model_cfg["name"]

@@ -124,16 +124,63 @@ class TapeMachine:
         n, HW, Cc = op.n_img, op.OH * op.OW, op.N
         Pa = P if op.seg[0].a.pstride != 0 else 1
         x = self.view(op.seg[0].a, Pa, n * HW * Cc).reshape(Pa, n, HW, Cc)
-        self.view(op.out, Pa, n * Cc).copy_((x.sum(2) * op.fscale).reshape(Pa, n * Cc))
+        self.view(op.out, Pa, n * Cc).copy_((x.sum(2) / HW).reshape(Pa, n * Cc))   # exact 1/HW (op.fscale is a C float)
 
     def pool_bwd(self, op, P):
         n, HW, Cc = op.n_img, op.OH * op.OW, op.N
         g = self.view(op.seg[0].a, P, n * Cc).reshape(P, n, 1, Cc)
-        v = (g * op.fscale).expand(P, n, HW, Cc).reshape(P, n * HW, Cc)
+        v = (g / HW).expand(P, n, HW, Cc).reshape(P, n * HW, Cc)
         if op.dphi.space != nv.SP_NONE:
             v = v * self.view(op.dphi, 1, n * HW * Cc).reshape(1, n * HW, Cc)
         self.view(op.out, P, n * HW * Cc).copy_(v.reshape(P, -1))
         self._reds(op, v, P, n * HW, Cc)
+
+    def _maxpool_geom(self, op):
+        g = op.seg[0]
+        return op.n_img, g.IH, g.IW, op.OH, op.OW, op.N, g.KH, g.KW, g.stride, g.pad_h, g.pad_w
+
+    def maxpool_primal(self, op):
+        n, IH, IW, OH, OW, Cc, KH, KW, st, ph, pw = self._maxpool_geom(op)
+        x = self.view(op.seg[0].a, 1, n * IH * IW * Cc).reshape(n, IH, IW, Cc)
+        out = torch.full((n, OH, OW, Cc), -3.0e38, dtype=F64)
+        am = torch.full((n, OH, OW, Cc), -1.0, dtype=F64)
+        for kh in range(KH):
+            for kw in range(KW):
+                for oh in range(OH):
+                    ih = oh * st + kh - ph
+                    if ih < 0 or ih >= IH:
+                        continue
+                    for ow in range(OW):
+                        iw = ow * st + kw - pw
+                        if iw < 0 or iw >= IW:
+                            continue
+                        v = x[:, ih, iw, :]
+                        better = v > out[:, oh, ow, :]
+                        out[:, oh, ow, :] = torch.where(better, v, out[:, oh, ow, :])
+                        am[:, oh, ow, :] = torch.where(better, torch.full_like(v, float(ih * IW + iw)), am[:, oh, ow, :])
+        self.view(op.out, 1, n * OH * OW * Cc).copy_(out.reshape(1, -1))
+        self.view(op.aux0, 1, n * OH * OW * Cc).copy_(am.reshape(1, -1))
+
+    def maxpool_fwd(self, op, P):
+        n, IH, IW, OH, OW, Cc, KH, KW, st, ph, pw = self._maxpool_geom(op)
+        x = self.view(op.seg[0].a, P, n * IH * IW * Cc).reshape(P, n, IH * IW, Cc)
+        am = self.view(op.aux0, 1, n * OH * OW * Cc).reshape(n, OH * OW, Cc).long()
+        idx = am.clamp_min(0).unsqueeze(0).expand(P, -1, -1, -1)
+        out = torch.gather(x, 2, idx) * (am >= 0).unsqueeze(0)
+        self.view(op.out, P, n * OH * OW * Cc).copy_(out.reshape(P, -1))
+
+    def maxpool_bwd(self, op, P):
+        n, IH, IW, OH, OW, Cc, KH, KW, st, ph, pw = self._maxpool_geom(op)
+        g = self.view(op.seg[0].a, P, n * OH * OW * Cc).reshape(P, n, OH * OW, Cc)
+        am = self.view(op.aux0, 1, n * OH * OW * Cc).reshape(n, OH * OW, Cc).long()
+        out = torch.zeros(P, n, IH * IW, Cc, dtype=F64)
+        idx = am.clamp_min(0).unsqueeze(0).expand(P, -1, -1, -1)
+        out.scatter_add_(2, idx, g * (am >= 0).unsqueeze(0))
+        v = out.reshape(P, n * IH * IW, Cc)
+        if op.dphi.space != nv.SP_NONE:
+            v = v * self.view(op.dphi, 1, n * IH * IW * Cc).reshape(1, n * IH * IW, Cc)
+        self.view(op.out, P, n * IH * IW * Cc).copy_(v.reshape(P, -1))
+        self._reds(op, v, P, n * IH * IW, Cc)
 
     def primal_post(self, op):
         R, N = op.n_img * op.OH * op.OW, op.N
@@ -202,6 +249,12 @@ class TapeMachine:
             self.softmax(op)
         elif k == nv.OP_HEAD:
             self.head(op, P, mode, c)
+        elif k == nv.OP_MAXPOOL_PRIMAL:
+            self.maxpool_primal(op)
+        elif k == nv.OP_MAXPOOL_FWD:
+            self.maxpool_fwd(op, P)
+        elif k == nv.OP_MAXPOOL_BWD:
+            self.maxpool_bwd(op, P)
         else:
             raise ValueError(k)
 

@@ -11,7 +11,7 @@ import torch
 
 from lip_amd import _native as nv
 from lip_amd.engine import LinearizedNet, build_consts
-from lip_amd.scalemodels import LargeClassifier, ResNet1M
+from lip_amd.scalemodels import LargeClassifier, ResNet1M, ResNet50
 from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
 from lip_amd.utils import flatten_nn_params
 from tape_emulator import TapeMachine
@@ -33,6 +33,10 @@ def _cases():
                         torch.rand(3, 8, 8, 3, dtype=F64, generator=g), "classifier", 2),
         "resnet_small": (ResNet1M(10, input_shape=(16, 16, 3), widths=(32, 64, 128), blocks_per_stage=1),
                          torch.rand(5, 16, 16, 3, dtype=F64, generator=g), "classifier", 3),
+        "resnet50_tiny": (ResNet50(6, input_shape=(20, 20, 3), stem=8, widths=(4, 8), blocks=(2, 1)),
+                          torch.rand(2, 20, 20, 3, dtype=F64, generator=g), "classifier", 2),
+        "resnet50_small": (ResNet50(100, input_shape=(32, 32, 3), stem=16, widths=(16, 32), blocks=(1, 1)),
+                           torch.rand(3, 32, 32, 3, dtype=F64, generator=g), "classifier", 2),
     }
 
 

@@ -7,7 +7,7 @@ import torch
 
 from lip_amd import _native as nv
 from lip_amd.engine import build_consts, compile_net
-from lip_amd.scalemodels import LargeClassifier, ResNet1M
+from lip_amd.scalemodels import LargeClassifier, ResNet1M, ResNet50
 from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
 from lip_amd.utils import flatten_nn_params
 from oracle.ggn import compute_ggn_vp, compute_W_vps
@@ -21,6 +21,8 @@ CASES = {
     "large": (LargeClassifier((6, 6, 1), [24, 16], 2, 5), torch.rand(4, 6, 6, 1, dtype=F64, generator=G), "classifier", 11),
     "resnet": (ResNet1M(4, input_shape=(8, 8, 3), widths=(4, 8, 12), blocks_per_stage=2),
                torch.rand(3, 8, 8, 3, dtype=F64, generator=G), "classifier", None),
+    "resnet50_tiny": (ResNet50(6, input_shape=(20, 20, 3), stem=8, widths=(4, 8), blocks=(2, 1)),
+                      torch.rand(2, 20, 20, 3, dtype=F64, generator=G), "classifier", 9),
 }
 
 
@@ -42,16 +44,16 @@ def test_tapes_reproduce_oracle(name):
     Y = tm.ggn_vp(V, N / n * math.exp(-lv), 0.37)
     vp = compute_ggn_vp(st, Z, model_type, full_set_size=full)
     Yo = torch.stack([vp(v) + 0.37 * v for v in V])
-    assert torch.allclose(Y, Yo, rtol=1e-10, atol=1e-12 * Yo.abs().max().item())
+    assert (Y - Yo).abs().max() <= 1e-11 * Yo.abs().max(), (Y - Yo).abs().max()
     Wf, WTf = compute_W_vps(st, Z, model_type, full_set_size=full)
     c = math.sqrt(N / n) * math.exp(-0.5 * lv)
     U = tm.jvp(V, nv.HEAD_LT, c)
     Uo = torch.stack([WTf(v).reshape(n, -1) for v in V])
-    assert torch.allclose(U, Uo, rtol=1e-10, atol=1e-12)
+    assert (U - Uo).abs().max() <= 1e-11 * Uo.abs().max().clamp_min(1.0)
     Ur = torch.randn(P, n, cn.K, dtype=F64, generator=torch.Generator().manual_seed(2))
     Yw = tm.vjp(Ur, nv.HEAD_L, c)
     Ywo = torch.stack([Wf(u if model_type == "classifier" else u.reshape(n)) for u in Ur])
-    assert torch.allclose(Yw, Ywo, rtol=1e-10, atol=1e-12 * Ywo.abs().max().item())
+    assert (Yw - Ywo).abs().max() <= 1e-11 * Ywo.abs().max()
 
 
 def test_resnet1m_layout_matches_survey():
@@ -67,3 +69,12 @@ def test_resnet1m_layout_matches_survey():
     fl = sum(tape_flops_per_probe(cn).values())
     first = 32 * 32 * 27 * 32
     assert fl == 50 * (8 * 162_366_720 - 4 * first)
+
+
+def test_resnet50_parameter_count():
+    """BASELINE configs[4]: the locally defined ResNet-50 has torchvision's parameter count (25 557 032 trainable
+    incl. BN affine parameters; running statistics are not part of theta)."""
+    net = ResNet50(1000)
+    st = create_state(net, 0)
+    flat, _ = flatten_nn_params(st.params)
+    assert flat.numel() == 25_557_032
