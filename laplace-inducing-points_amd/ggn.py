@@ -80,6 +80,33 @@ def _logvar(state):
     return float(torch.as_tensor(state.params["logvar"]["logvar"]).detach().cpu())
 
 
+class ExampleChunkedGGN:
+    """GGN block operator over a data set too large for one engine binding: the examples are split into chunks,
+    each chunk gets its own engine (cached primal pass), and the per-chunk products are summed — the data sum of
+    ``src/ggn.py:144`` is associative, so this is the single-GPU twin of the multi-GPU shard (``dist.py``)."""
+
+    def __init__(self, state, Z, model_type, full_set_size=None, example_chunk=64, workspace_bytes=8 << 30):
+        self.engines = []
+        n = Z.shape[0]
+        for s in range(0, n, example_chunk):
+            self.engines.append(LinearizedNet(state, Z[s:s + example_chunk], model_type, workspace_bytes=workspace_bytes))
+        N = full_set_size or n
+        self.scale = N / n * (math.exp(-_logvar(state)) if model_type == "regressor" else 1.0)
+        self.D = self.engines[0].D
+        self.engine = self.engines[0]
+
+    def __call__(self, V, alpha: float = 0.0):
+        single = V.dim() == 1
+        Vb = V[None] if single else V
+        Vb = Vb.to(device=self.engines[0].device, dtype=torch.float32).contiguous()
+        Y = self.engines[0].ggn_vp(Vb, self.scale, alpha)
+        for eng in self.engines[1:]:
+            Y += eng.ggn_vp(Vb, self.scale, 0.0)
+        return Y[0] if single else Y
+
+    rows = __call__
+
+
 def materialize_factor(eng: LinearizedNet, c: float = 1.0, block: Optional[int] = None) -> torch.Tensor:
     """Wm (d, D) with rows c * J_i^T L_i e_k — the square-root factor W^T of the GGN (``src/ggn.py:9-93``)
     written out: d = M K engine rows (one backward sweep with the one-hot block as cotangents)."""

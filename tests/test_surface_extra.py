@@ -153,3 +153,44 @@ def test_factor_mode_equals_matrix_free(classification_2d_data, classifier_state
     ref = torch.stack([ref_vp(v) for v in V])
     for out in (a, b, c):
         assert torch.allclose(cpu64(out), ref, rtol=2e-4, atol=2e-4 * ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_example_chunked_operator(classification_2d_data, classifier_state):
+    """Summing per-chunk engines over a split of Z == one engine over all of Z (ragged last chunk)."""
+    import src.ggn as hg
+    X, y = classification_2d_data
+    X = X[::7]                                            # 29 points -> chunks 8, 8, 8, 5
+    st = classifier_state.to(device="cuda", dtype=torch.float32)
+    V = torch.randn(3, 354, generator=torch.Generator().manual_seed(0)).cuda()
+    full = hg.compute_ggn_vp(st, X.cuda().float(), "classifier", full_set_size=300)(V)
+    chunked = hg.ExampleChunkedGGN(st, X.cuda().float(), "classifier", full_set_size=300, example_chunk=8)(V)
+    assert torch.allclose(full, chunked, rtol=1e-4, atol=1e-4 * full.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_resnet50_real_architecture_properties():
+    """BASELINE configs[4] architecture at full width/depth (25.6 M parameters, K = 1000) on 64 x 64 synthetic
+    images: linearity, symmetry and PSD of the GGN block, and one probe against the example-batched float64
+    oracle (the ImageNet-resolution run only changes the pixel counts)."""
+    from lip_amd import krylov
+    from lip_amd.scalemodels import ResNet50
+    from lip_amd.toymodels import create_state
+    import src.ggn as hg
+    net = ResNet50(1000, input_shape=(64, 64, 3))
+    st64 = create_state(net, 0, dtype=torch.float64)
+    Z = torch.randn(3, 64, 64, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    vp = hg.compute_ggn_vp(st64.to(device="cuda", dtype=torch.float32), Z.cuda().float(), "classifier", full_set_size=10000)
+    D = vp.engine.D
+    assert D == 25_557_032
+    V = krylov.fill_rademacher(4, D, 3, "cuda")
+    Y = vp(V)
+    assert torch.isfinite(Y).all()
+    Gm = V @ Y.T
+    assert torch.allclose(Gm, Gm.T, rtol=2e-3, atol=2e-3 * Gm.abs().max().item())
+    assert torch.linalg.eigvalsh(0.5 * (Gm + Gm.T).double()).min() > -2e-3 * Gm.abs().max().item()
+    lin = vp((V[0] - 2.0 * V[1])[None])[0]
+    assert torch.allclose(lin, Y[0] - 2.0 * Y[1], rtol=2e-3, atol=2e-3 * Y.abs().max().item())
+    ref = og.compute_ggn_vp_batched(st64, Z, "classifier", full_set_size=10000)(cpu64(V[0]))
+    err = (cpu64(Y[0]) - ref).abs().max() / ref.abs().max()
+    assert err < 5e-4, err
