@@ -175,3 +175,63 @@ def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[
         active = (rr > atol2).to(torch.int32) * active
         it += 1
     return X, dict(iterations=it, residual_norm=torch.sqrt(rr))
+
+
+def _basis(P: int, k: int, N: int, dev):
+    ldq = (N + 3) // 4 * 4
+    return torch.empty(P, k, ldq, device=dev, dtype=torch.float32), ldq
+
+
+def _cgs2(lib, Qbuf, ldq, w, P, j, k, N, c1, c2, nrm2, st):
+    """w -= Q_j^T (Q_j w), twice; returns with nrm2 = ||w||^2 (blocked classical Gram-Schmidt, 2 passes)."""
+    for c in (c1, c2):
+        nv.check(lib.lip_multi_dot(nv.ptr(Qbuf), nv.ptr(w), nv.ptr(c), P, j, k, N, ldq, st), "lip_multi_dot")
+        nv.check(lib.lip_multi_axpy_norm(nv.ptr(Qbuf), nv.ptr(c), nv.ptr(w), nv.ptr(nrm2), P, j, k, N, ldq, st),
+                 "lip_multi_axpy_norm")
+
+
+def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: int):
+    """k-step Golub-Kahan bidiagonalisation with full re-orthogonalisation, P recurrences at once, started in
+    the domain: A V = U B with B (k, k) upper bidiagonal (matfree ``decomp.bidiag`` as the reference calls it,
+    ``src/train_inducing.py:156``).  ``matvec``: (P, N) -> (P, n_out); ``vecmat``: (P, n_out) -> (P, N).
+    Returns (alphas (P, k), betas (P, k-1))."""
+    lib = nv.load()
+    P, N = _chk(V0).shape
+    st = nv.stream_ptr()
+    dev = V0.device
+    Vb, ldv = _basis(P, k, N, dev)
+    Ub, ldu = _basis(P, k, n_out, dev)
+    alphas = torch.zeros(P, k, device=dev, dtype=torch.float32)
+    betas = torch.zeros(P, max(k - 1, 0), device=dev, dtype=torch.float32)
+    c1 = torch.empty(P, k, device=dev, dtype=torch.float32)
+    c2 = torch.empty(P, k, device=dev, dtype=torch.float32)
+    nrm2 = bdot(V0, V0)
+    nv.check(lib.lip_scale_store(nv.ptr(V0), nv.ptr(nrm2), nv.ptr(Vb), 0, P, k, N, ldv, st), "lip_scale_store")
+    for j in range(k):
+        v = Vb[:, j, :N].contiguous()
+        u = _chk(matvec(v).contiguous())
+        if j > 0:
+            _cgs2(lib, Ub, ldu, u, P, j, k, n_out, c1, c2, nrm2, st)
+        else:
+            nrm2 = bdot(u, u)
+        alphas[:, j] = torch.sqrt(nrm2)
+        nv.check(lib.lip_scale_store(nv.ptr(u), nv.ptr(nrm2), nv.ptr(Ub), j, P, k, n_out, ldu, st), "lip_scale_store")
+        if j + 1 < k:
+            w = _chk(vecmat(Ub[:, j, :n_out].contiguous()).contiguous())
+            _cgs2(lib, Vb, ldv, w, P, j + 1, k, N, c1, c2, nrm2, st)
+            betas[:, j] = torch.sqrt(nrm2)
+            nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(nrm2), nv.ptr(Vb), j + 1, P, k, N, ldv, st), "lip_scale_store")
+    return alphas, betas
+
+
+def slq_logdet_product(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: int) -> torch.Tensor:
+    """matfree ``funm.integrand_funm_product_logdet(bidiag(k))``: per probe ||v||^2 e1^T log(B^T B) e1, an
+    unbiased-per-probe quadrature of log det(A^T A) (``src/train_inducing.py:156-162``).  Returns (P,) float64."""
+    length2 = bdot(V0, V0).double()
+    alphas, betas = bidiag(matvec, vecmat, V0, k, n_out)
+    B = torch.diag_embed(alphas.double())
+    if betas.shape[-1] > 0:
+        B = B + torch.diag_embed(betas.double(), 1)
+    _, S, Vt = torch.linalg.svd(B)
+    fx = torch.log(S ** 2)
+    return length2 * (Vt[:, :, 0] ** 2 * fx).sum(-1)

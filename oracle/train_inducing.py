@@ -1,0 +1,47 @@
+"""Oracle restatement of the objective VALUES of ``src/train_inducing.py`` (TEST INFRASTRUCTURE).
+``alternative_objective_scalable`` (``:87-173``) literal: Woodbury S_z^-1, ``hutchpp_v2`` on S S_z^-1, SLQ log-det by
+``integrand_funm_product_logdet(bidiag(k))`` averaged over the first ``slq_samples`` probes.  The bidiagonalisation
+log-det is "parity unpinned" against the reference (no reference fixture exercises it); here it is checked against
+the exact slogdet."""
+import math
+
+import torch
+
+import lip_amd  # noqa: F401
+from lip_amd.utils import flatten_nn_params
+
+from .ggn import build_WTW, compute_W_vps
+from .lla import compute_curvature_approx
+from .matfree import bidiag, integrand_funm_product_logdet
+from .stochtrace import hutchpp_v2
+
+
+def alternative_objective_scalable(Z, X, state, alpha, model_type, probes, full_set_size, slq_samples=2,
+                                   slq_num_matvecs=None, logdet_beta=True):
+    N = full_set_size
+    M = Z.shape[0]
+    beta = N / M
+    alpha_inv, beta_inv = 1.0 / alpha, 1.0 / beta
+    flat, _ = flatten_nn_params(state.params)
+    D = flat.numel()
+    S_vp = compute_curvature_approx(state, X, alpha=alpha, model_type=model_type, full_set_size=N)
+    Wz, WzT = compute_W_vps(state, Z, model_type=model_type, full_set_size=None)
+    dummy = WzT(torch.zeros(D, dtype=flat.dtype))
+    inner, d_z = tuple(dummy.shape), dummy.numel()
+    WzTWz = build_WTW(Wz, WzT, inner, d_z, dtype=flat.dtype, block=1)
+    I = torch.eye(d_z, dtype=flat.dtype)
+
+    def Sz_inv(v):
+        u = WzT(v).reshape(d_z)
+        x = torch.linalg.solve(beta_inv * I + alpha_inv * WzTWz, u)
+        return alpha_inv * v - alpha_inv ** 2 * Wz(x.reshape(inner))
+
+    st = probes.shape[0]
+    trace_term = hutchpp_v2(lambda v: S_vp(Sz_inv(v)), lambda _: probes, s1=st - 16, s2=16)
+    k = slq_num_matvecs if slq_num_matvecs is not None else int(M * 0.8)
+    sa, sb = math.sqrt(alpha), (math.sqrt(beta) if logdet_beta else 1.0)
+    A = lambda v: torch.cat([sa * v, sb * WzT(v).reshape(d_z)])
+    AT = lambda u: sa * u[:D] + Wz((sb * u[D:]).reshape(inner))
+    quad = integrand_funm_product_logdet(bidiag(k))
+    logdet_term = torch.stack([quad(A, AT, p) for p in probes[:slq_samples]]).mean()
+    return float(logdet_term + trace_term), float(logdet_term), float(trace_term)
