@@ -185,6 +185,27 @@ def main():
                             seconds=ts, at_2000_samples=2000 / ts2, includes="one-off factor build (d backward rows) + float64 Gram + exact small-space f(A), then W^T / W as GEMMs",
                             finite=bool(torch.isfinite(S).all().item()))
 
+    # ---- opt-in split-precision MFMA mode (bf16x3): same workload, implicit-GEMM kernels on bf16 matrix cores ------
+    split_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        from lip_amd.engine import set_precision
+        Y32 = eng.ggn_vp(V, scale, alpha)
+        try:
+            set_precision("bf16x3")
+            eng.ggn_vp(V, scale, alpha)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                Ys = eng.ggn_vp(V, scale, alpha)
+            torch.cuda.synchronize()
+            t_s = (time.perf_counter() - t1) / 3
+        finally:
+            set_precision("f32")
+        split_line = dict(value=P / t_s, unit="GGN-vp/s", ms_per_step=1e3 * t_s, dtype="bf16x3",
+                          rel_diff_vs_f32=float(((Ys - Y32).abs().max() / Y32.abs().max()).item()),
+                          note="opt-in lip_set_precision(1): operands split hi+lo in bf16, 3 bf16 MFMAs per product, "
+                               "f32 accumulate (igemm kernels only so far); NOT the headline: the default is exact f32")
+
     # ---- opt-in materialised-factor mode (same results, two plain GEMMs; valid while d*D*4 B fits HBM) -------
     factor_line = None
     if args.samples > 0 and rank == 0 and world == 1:
@@ -237,7 +258,7 @@ def main():
                                          "full_set_size=49000; data sum sharded over ranks, one all-reduce per matvec",
                                 examples_per_gpu=n, probes=P, D=eng.D, probe_chunk=eng.chunk,
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:

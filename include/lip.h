@@ -109,6 +109,11 @@ typedef struct lip_engine lip_engine_t;
 int lip_abi_version(void);                 /* bumps when this header changes                     */
 const char* lip_last_error(void);          /* text of the last failure on this thread            */
 int lip_sizeof_op(void);                   /* sizeof(lip_op_t): lets the ctypes mirror self-check */
+/* arithmetic of the MFMA kernels (process-wide): 0 = exact f32 MFMA (default, dtype "f32");
+ * 1 = split-precision operands x = hi + lo in bf16, three bf16 MFMAs per product with f32 accumulation
+ *     ("bf16x3": ~1e-5 relative error per product, ~5x fewer matrix-pipe cycles).                     */
+int lip_set_precision(int32_t mode);
+int lip_get_precision(void);
 
 /* ---- engine: one per (network, theta_MAP, data slice Z) binding on one device --------
  * Replaces the closure factories compute_ggn_vp / compute_W_vps (src/ggn.py:97,9): they

@@ -54,6 +54,8 @@ SIGNATURES = {
     "lip_abi_version": (C.c_int, []),
     "lip_last_error": (C.c_char_p, []),
     "lip_sizeof_op": (C.c_int, []),
+    "lip_set_precision": (C.c_int, [C.c_int32]),
+    "lip_get_precision": (C.c_int, []),
     "lip_engine_create": (C.c_int, [C.POINTER(_V), C.c_int64, C.c_int32, C.c_int32]),
     "lip_engine_destroy": (C.c_int, [_V]),
     "lip_engine_set_tape": (C.c_int, [_V, C.c_int32, C.POINTER(Op), C.c_int32]),

@@ -293,6 +293,8 @@ extern "C" {
 int lip_abi_version(void) { return 2; }
 const char* lip_last_error(void) { return g_err; }
 int lip_sizeof_op(void) { return (int)sizeof(lip_op_t); }
+int lip_set_precision(int32_t mode) { if (mode != 0 && mode != 1) { set_error("lip_set_precision: mode must be 0 (f32) or 1 (bf16x3)"); return LIP_ERR_ARG; } set_precision_mode(mode); return LIP_OK; }
+int lip_get_precision(void) { return precision_mode(); }
 
 int lip_engine_create(lip_engine_t** out, int64_t D, int32_t n_img, int32_t K) {
   if (!out || D <= 0 || n_img <= 0 || K <= 0) { set_error("lip_engine_create: bad argument"); return LIP_ERR_ARG; }

@@ -127,6 +127,8 @@ hipError_t launch_head(const HeadP& p, int P, hipStream_t st);
 hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st);
 
 void set_error(const char* fmt, ...);
+int precision_mode();
+void set_precision_mode(int m);
 
 // ---- wave / block reductions (wave = 64 lanes on gfx950) --------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -60,6 +60,65 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ As, const f
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-precision ("bf16x3") operand path: every f32 operand x is stored in LDS as two bf16 planes,
+// hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|), and a 16-deep K-tile of a 32x32 tile is
+//   acc += a_lo*b_hi + a_hi*b_lo + a_hi*b_hi        (3 x v_mfma_f32_32x32x16_bf16, f32 accumulate)
+// i.e. 96 matrix-pipe cycles instead of the 512 of eight v_mfma_f32_32x32x2_f32; the dropped lo*lo term and the
+// roundings bound the error of a product by ~3 * 2^-18 |a b| (1.1e-5).  LDS rows hold the 16 k-values of one
+// m (or n) as 32 B of bf16 padded to 48 B: the 16-byte fragment of lane l (row l&31, k-half l>>5) is one
+// conflict-free ds_read_b128 (slot = 3*row mod 16 is a bijection on every b128 lane group).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SROW = 12;                       // floats per LDS row of the split layout (48 B)
+
+__device__ __forceinline__ void split_store4(float* plane_hi, float* plane_lo, int row, int k4, float x0, float x1,
+                                             float x2, float x3) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 hi, lo;
+  hi[0] = (__bf16)x0; hi[1] = (__bf16)x1; hi[2] = (__bf16)x2; hi[3] = (__bf16)x3;
+  lo[0] = (__bf16)(x0 - (float)hi[0]); lo[1] = (__bf16)(x1 - (float)hi[1]);
+  lo[2] = (__bf16)(x2 - (float)hi[2]); lo[3] = (__bf16)(x3 - (float)hi[3]);
+  *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(plane_hi + row * SROW) + k4) = hi;
+  *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(plane_lo + row * SROW) + k4) = lo;
+}
+
+__device__ __forceinline__ void split_store1(float* plane_hi, float* plane_lo, int row, int k, float x) {
+  const __bf16 hi = (__bf16)x;
+  const __bf16 lo = (__bf16)(x - (float)hi);
+  reinterpret_cast<__bf16*>(plane_hi + row * SROW)[k] = hi;
+  reinterpret_cast<__bf16*>(plane_lo + row * SROW)[k] = lo;
+}
+
+// One 16-deep K-tile on the split LDS images: As = [hi plane BM rows | lo plane BM rows], Bs likewise (BN rows).
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void mfma_sweep_split(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                 f32x16 (&acc)[TM][TN], int wm, int wn, int lane) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const int l31 = lane & 31, lh = lane >> 5;
+  bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = (wm * TM + tm) * 32 + l31;
+    ah[tm] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(As + row * SROW) + 8 * lh);
+    al[tm] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(As + (BM + row) * SROW) + 8 * lh);
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int row = (wn * TN + tn) * 32 + l31;
+    bh[tn] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(Bs + row * SROW) + 8 * lh);
+    bl[tn] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(Bs + (BN + row) * SROW) + 8 * lh);
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+    }
+}
+
 // Software pipeline shared by the fast kernels: LDS is double buffered and two register tile sets are
 // in flight, so the global loads of K-tile t+2 are issued before the MFMA sweep of tile t and only
 // waited for after the sweep of tile t+1 (a counted vmcnt: the loads are branch-free — masked rows read
@@ -409,13 +468,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 // ------------------------------------------------------------------------------------------
 // ABL (timing experiments only, results are wrong for ABL != 0): 1 = no global loads in the K loop,
 // 2 = also no LDS stores / barriers, 3 = MFMA only (operands from registers).
-template <int WM, int WN, int TM, int TN, int ABL = 0>
+template <int WM, int WN, int TM, int TN, int ABL = 0, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
   constexpr int LDA = BM + 2, LDB = BN;
-  __shared__ float As[2 * BK * LDA];
-  __shared__ float Bs[2 * BK * LDB];
+  constexpr int ASZ = SPLIT ? 2 * BM * SROW : BK * LDA;      // floats per LDS buffer
+  constexpr int BSZ = SPLIT ? 2 * BN * SROW : BK * LDB;
+  __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
   __shared__ float redbuf[2 * BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -518,6 +579,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
     if (ABL >= 2 && !first_store) return;
     first_store = false;
+    if (SPLIT) {
+#pragma unroll
+      for (int j = 0; j < AQ; ++j) {
+        const int m = (tid + j * NT) >> 2;
+        split_store4(Asb, Asb + BM * SROW, m, kq4, areg[4 * j], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+      }
+#pragma unroll
+      for (int j = 0; j < BE; ++j) {
+        const int e = tid + j * NT;
+        const int k = e / BN, nn = e - k * BN;
+        split_store1(Bsb, Bsb + BN * SROW, nn, k, breg[j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
       const int m = (tid + j * NT) >> 2;
@@ -580,9 +655,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] += acc2[tm][tn];
     }
   } else {
-    pipelined_k_loop<AE, BE, BK * LDA, BK * LDB>(
+    pipelined_k_loop<AE, BE, ASZ, BSZ>(
         ktiles, As, Bs, load_tile, store_tile, advance,
-        [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
+        [&](const float* Asb, const float* Bsb) {
+          if (SPLIT) mfma_sweep_split<WM, WN, TM, TN>(Asb, Bsb, acc, wm, wn, lane);
+          else mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane);
+        });
   }
   if (ABL == 6) {                                    // keep the accumulators live with one store per lane
     float t = 0.f;
@@ -917,6 +995,17 @@ static const float* zero_page() {
   return pages[dev];
 }
 
+// 0: exact f32 MFMA (default); 1: split-precision bf16x3 operands (lip_set_precision / LIP_PRECISION=bf16x3)
+static int g_precision = -1;
+int precision_mode() {
+  if (g_precision < 0) {
+    const char* e = getenv("LIP_PRECISION");
+    g_precision = (e && (e[0] == 'b' || e[0] == '1')) ? 1 : 0;
+  }
+  return g_precision;
+}
+void set_precision_mode(int m) { g_precision = m ? 1 : 0; }
+
 static int stagger_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("LIP_STAGGER"); v = e ? atoi(e) : 0; }   // measured: no gain (r11) -> off
@@ -960,6 +1049,7 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
     else if (abl == 5) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 5>), grid, dim3(T::NT), 0, st, q);
     else if (abl == 6) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 6>), grid, dim3(T::NT), 0, st, q);
     else if (abl == 7) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 7>), grid, dim3(T::NT), 0, st, q);
+    else if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 0, true>), grid, dim3(T::NT), 0, st, q);
     else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q);
   }
   else

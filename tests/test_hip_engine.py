@@ -131,3 +131,25 @@ def test_missing_netspec_fails_loudly():
     st = TrainState(params={"params": {"W": torch.ones(1, 1)}}, apply_fn=lambda p, x, **k: x)
     with pytest.raises(TypeError):
         LinearizedNet(st, torch.zeros(2, 1), "regressor")
+
+
+def test_split_precision_mode_accuracy():
+    """Opt-in bf16x3 MFMA path (lip_set_precision): stated tolerance 5e-5 * max|ref| against the float64 tape
+    semantics (measured ~6e-6); the default f32 path on the same inputs stays below 2e-6."""
+    from lip_amd.engine import get_precision, set_precision
+    net, Z, model_type, P = _cases()["resnet_small"]
+    state = create_state(net, 3, dtype=F64)
+    eng = LinearizedNet(state, Z, model_type, workspace_bytes=1 << 28, max_chunk=P)
+    flat, _ = flatten_nn_params(state.params)
+    tm = TapeMachine(eng.cn, flat, build_consts(eng.cn, state.params, state.batch_stats, "cpu", F64), Z, chunk=eng.chunk)
+    tm.primal()
+    V = torch.randn(P, eng.D, dtype=F64, generator=torch.Generator().manual_seed(1))
+    ref = tm.ggn_vp(V, 3.0, 0.2).clone()
+    try:
+        assert get_precision() == "f32"
+        e32 = _rel(eng.ggn_vp(V, 3.0, 0.2), ref)
+        set_precision("bf16x3")
+        e16 = _rel(eng.ggn_vp(V, 3.0, 0.2), ref)
+    finally:
+        set_precision("f32")
+    assert e32 < 2e-6 and e16 < 5e-5, (e32, e16)
