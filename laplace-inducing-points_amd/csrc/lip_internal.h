@@ -51,9 +51,8 @@ struct IgemmP {
   float* red0; long long red0_ps;
   float* red1; long long red1_ps;
   const float* xhat2;
-  int blocks_per_cu, stagger;           // first-round stagger (speed only)
   const float* zeros;                   // >= 16 floats of device zeros (masked gather rows)
-  int xcd_remap;                        // XCD-aware tile order (speed only)
+  unsigned long long* dbg;              // diagnostic s_memtime stamps (null in every real run)
 };
 
 struct WgradP {
@@ -65,7 +64,6 @@ struct WgradP {
   float* y; long long y_ps;             // Y + param offset, element [m*N + co]
   const float* scale;                   // per-channel [N] or null
   int ksplit;
-  int blocks_per_cu, stagger;           // first-round stagger (speed only)
   const float* zeros;
 };
 

@@ -20,6 +20,7 @@
 //   C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // LDS images are k-major (As[k][m], Bs[k][n]) so every MFMA operand read is 32 consecutive
 // dwords per half-wave: conflict-free ds_read_b32.
+#include <stdio.h>
 #include <stdlib.h>
 #include "lip_internal.h"
 
@@ -168,33 +169,17 @@ __device__ __forceinline__ void pipelined_k_loop(int T, float* As, float* Bs, Lo
   }
 }
 
-// First-round stagger.  All blocks of a launch have the same duration, so the B blocks co-resident on a
-// CU (and all CUs of the chip) would run their K loops and then their memory-bound epilogues in lockstep:
-// measured on MI355X as a chip-wide HBM burst during which every MFMA pipe idles (23 % of the launch).
-// Delaying the blocks of the first round by phase * (block duration / B) keeps memory and MFMA phases of
-// different blocks overlapped for the rest of the launch.  Speed only: no result depends on it.
-__device__ __forceinline__ void stagger_first_round(int ktiles, int mfma_per_ktile, int blocks_per_cu, int enabled) {
-  if (!enabled || blocks_per_cu <= 1) return;
-  const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
-  if (lin >= 256u * (unsigned)blocks_per_cu) return;             // later rounds inherit the stagger
-  const unsigned phase = ((lin >> 8) + lin) % (unsigned)blocks_per_cu;
-  // a block's waves share their SIMD with blocks_per_cu - 1 others: duration ~ B * ktiles * mfma * 64 cycles
-  long long cycles = (long long)phase * ktiles * mfma_per_ktile * 64 * enabled;   // enabled > 1: exaggerated (experiments)
-  while (cycles > 0) { __builtin_amdgcn_s_sleep(127); cycles -= 127 * 64; }
-}
-
 // Fused epilogue shared by the generic and the fast implicit-GEMM kernels.
-// The accumulators are drained in "phases" of 8 rows of one 32x32 tile.  Each phase needs operand loads
-// (xhat, residual, act') before its stores; phases are software pipelined with two register sets, so the
-// loads of phase t+1 are in flight while phase t is computed and stored — the 2..8 phases of a wave cost
-// about one loaded-memory latency in total instead of one each (measured: the serial form kept a block's
-// slot idle for ~16 % of the launch).
+// The accumulators are drained in phases of 8 rows of one 32x32 tile: first ALL operand loads of the phase
+// (xhat, residual, act') are issued into registers, then the results are computed and stored — a load never sits
+// behind a store that might alias it, so a phase costs one memory round trip instead of eight.
+// Measured on MI355X and rejected (no gain, more VGPRs): software-pipelining the phases with two register sets,
+// and issuing phase 0's loads before the K loop.
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[TM][TN], float* redbuf, int p, int r0,
                                                int n0, int wm, int wn, int lane, int tid) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BN = T::BN;
-  constexpr int NPH = TM * TN * 2;                 // phases: (tn, tm, half)
   const int N = prm.N, R = prm.R;
   const int l31 = lane & 31, lh = lane >> 5;
   const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
@@ -204,75 +189,55 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
   const float* __restrict__ res = prm.res ? prm.res + (long long)p * prm.res_ps : nullptr;
   float* __restrict__ out = prm.out + (long long)p * prm.out_ps;
   const bool has_e1 = prm.e1 != nullptr, has_r1 = prm.red1 != nullptr;
-
-  float sc[TN], e0v[TN], e1v[TN], s0[TN], s1[TN];
-  bool cv[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + (wn * TN + tn) * 32 + l31;
-    cv[tn] = col < N;
-    sc[tn] = (prm.scale && cv[tn]) ? prm.scale[col] : 1.f;
-    e0v[tn] = (prm.e0 && cv[tn]) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
-    e1v[tn] = (has_e1 && cv[tn]) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
-    s0[tn] = 0.f; s1[tn] = 0.f;
-  }
-
-  // phase ph -> (tn, tm, h); row of accumulator register reg = 8*h + q
-  auto row_of = [&](int ph, int q) -> int {
-    const int tm = (ph >> 1) % TM, h = ph & 1, reg = 8 * h + q;
-    return r0 + (wm * TM + tm) * 32 + 4 * lh + (reg & 3) + 8 * (reg >> 2);
-  };
-  auto issue = [&](int ph, float (&xv)[8], float (&rv)[8], float (&dv)[8], float (&x2)[8]) {
-    const int tn = ph / (2 * TM);
-    const int col = n0 + (wn * TN + tn) * 32 + l31;
+    const int cl = (wn * TN + tn) * 32 + l31;
+    const int col = n0 + cl;
+    const bool cv = col < N;
+    const float sc = (prm.scale && cv) ? prm.scale[col] : 1.f;
+    const float e0v = (prm.e0 && cv) ? prm.e0[(long long)p * prm.e0_ps + col] : 0.f;
+    const float e1v = (has_e1 && cv) ? prm.e1[(long long)p * prm.e1_ps + col] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = row_of(ph, q);
-      const bool ok = cv[tn] && r < R;
-      const unsigned idx = ok ? (unsigned)(r * N + col) : 0u;     // clamped: loads stay unconditional
-      xv[q] = has_e1 ? xhat[idx] : 0.f;
-      rv[q] = res ? res[idx] : 0.f;
-      dv[q] = dphi ? dphi[idx] : 1.f;
-      x2[q] = has_r1 ? xhat2[idx] : 0.f;
-    }
-  };
-  auto finish = [&](int ph, const float (&xv)[8], const float (&rv)[8], const float (&dv)[8], const float (&x2)[8]) {
-    const int tn = ph / (2 * TM), tm = (ph >> 1) % TM, h = ph & 1;
-    const int col = n0 + (wn * TN + tn) * 32 + l31;
+    for (int tm = 0; tm < TM; ++tm) {
+      const int rbase = r0 + (wm * TM + tm) * 32 + 4 * lh;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = row_of(ph, q);
-      if (cv[tn] && r < R) {
-        const float v = (acc[tm][tn][8 * h + q] * sc[tn] + e0v[tn] + e1v[tn] * xv[q] + rv[q]) * dv[q];
-        out[(unsigned)(r * N + col)] = v;
-        s0[tn] += v;
-        s1[tn] += v * x2[q];
+      for (int h = 0; h < 2; ++h) {
+        float xv[8], rv[8], dv[8], x2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int reg = 8 * h + q;
+          const int r = rbase + (reg & 3) + 8 * (reg >> 2);
+          const bool ok = cv && r < R;
+          const unsigned idx = ok ? (unsigned)(r * N + col) : 0u;     // clamped: loads stay unconditional
+          xv[q] = has_e1 ? xhat[idx] : 0.f;
+          rv[q] = res ? res[idx] : 0.f;
+          dv[q] = dphi ? dphi[idx] : 1.f;
+          x2[q] = has_r1 ? xhat2[idx] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int reg = 8 * h + q;
+          const int r = rbase + (reg & 3) + 8 * (reg >> 2);
+          if (cv && r < R) {
+            const float v = (acc[tm][tn][reg] * sc + e0v + e1v * xv[q] + rv[q]) * dv[q];
+            out[(unsigned)(r * N + col)] = v;
+            s0 += v;
+            s1 += v * x2[q];
+          }
+        }
       }
     }
-  };
-
-  float xA[8], rA[8], dA[8], yA[8], xB[8], rB[8], dB[8], yB[8];
-  issue(0, xA, rA, dA, yA);
-#pragma unroll
-  for (int ph = 0; ph < NPH; ph += 2) {
-    issue(ph + 1, xB, rB, dB, yB);                  // NPH is even: phase ph+1 always exists
-    finish(ph, xA, rA, dA, yA);
-    if (ph + 2 < NPH) issue(ph + 2, xA, rA, dA, yA);
-    finish(ph + 1, xB, rB, dB, yB);
-  }
-
-  if (do_red) {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int cl = (wn * TN + tn) * 32 + l31;
-      float a0 = s0[tn], a1 = s1[tn];
-      a0 += __shfl_xor(a0, 32, 64);
-      a1 += __shfl_xor(a1, 32, 64);
+    if (do_red) {
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
       if (lh == 0) {
-        atomicAdd(&redbuf[cl], a0);
-        atomicAdd(&redbuf[BN + cl], a1);
+        atomicAdd(&redbuf[cl], s0);
+        atomicAdd(&redbuf[BN + cl], s1);
       }
     }
+  }
+  if (do_red) {
     __syncthreads();
     for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
@@ -466,9 +431,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 //   once (branch-free, host-precomputed segment scalars) and reused for the C/16 K-tiles of the tap;
 //   B and LDS offsets are loop invariant.  ~8 non-MFMA instructions per MFMA instead of ~30.
 // ------------------------------------------------------------------------------------------
-// ABL (timing experiments only, results are wrong for ABL != 0): 1 = no global loads in the K loop,
-// 2 = also no LDS stores / barriers, 3 = MFMA only (operands from registers).
-template <int WM, int WN, int TM, int TN, int ABL = 0, bool SPLIT = false>
+template <int WM, int WN, int TM, int TN, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
@@ -483,14 +446,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   const int wm = wave / WN, wn = wave % WN;
   const int N = prm.N, R = prm.R;
   const int tiles_n = (N + BN - 1) / BN;
-  // XCD-aware tile order (speed only): blocks b and b + 8 share an XCD under round-robin dispatch, so XCD x
-  // gets the contiguous tile range [x*q + min(x, r), ...) (bijective for any tile count): neighbouring row
-  // tiles share their conv halo rows through one L2 instead of fetching them into eight.
-  int bid = blockIdx.x;
-  if (prm.xcd_remap) {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
+  const int bid = blockIdx.x;   // (an XCD-aware tile order was measured on MI355X: no gain — rejected)
   const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
   const int p = blockIdx.y;
   const int r0 = tile_m * BM, n0 = tile_n * BN;
@@ -557,10 +513,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
       rowoff[j] = rowok[j] ? ((vi[j] * sIH + ih) * sIW + iw) * sC + kq4 : 0;
     }
   };
-  bool first_load = true;
   auto load_tile = [&](float (&areg)[AE], float (&breg)[BE]) {
-    if (ABL >= 1 && !first_load) return;
-    first_load = false;
     const float* ap = abase + c0;
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
@@ -575,10 +528,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
       breg[j] = *src;
     }
   };
-  bool first_store = true;
   auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
-    if (ABL >= 2 && !first_store) return;
-    first_store = false;
     if (SPLIT) {
 #pragma unroll
       for (int j = 0; j < AQ; ++j) {
@@ -620,60 +570,27 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 
   int ktiles = 0;
   for (int q = 0; q < prm.nseg; ++q) ktiles += prm.seg[q].Ktot / BK;
-  stagger_first_round(ktiles, TM * TN * (BK / 2), prm.blocks_per_cu, prm.stagger);
+  unsigned long long t_start = 0, t_loop_end = 0;
+  const unsigned dbg_lin = blockIdx.x + blockIdx.y * gridDim.x;
+  const bool dbg_on = prm.dbg != nullptr && dbg_lin < 8192 && tid == 0;
+  if (dbg_on) t_start = __builtin_amdgcn_s_memtime();
   begin_segment();
   set_tap();
-  if (ABL >= 3) {   // 3: MFMA only; 4: 4x the MFMAs; 5: two accumulators; 6: MFMA only and no epilogue; 7: randomised loop length
-    float fa = (float)tid, fb = (float)lane;
-    if (ABL == 7) {   // per-block K-loop length in [0.5, 1.5] x nominal (mean 1): breaks any lockstep between blocks
-      unsigned h = (blockIdx.x * 2654435761u) ^ (blockIdx.y * 40503u);
-      h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
-      ktiles = max(1, (int)(ktiles * (0.5f + (float)(h & 1023) / 1023.0f)));
-    }
-    f32x16 acc2[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc2[tm][tn] = acc[tm][tn];
-    do {
-#pragma unroll
-      for (int rep = 0; rep < (ABL == 4 ? 4 : 1); ++rep)
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk)
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-              if ((ABL == 5) && (kk & 1)) acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc2[tm][tn], 0, 0, 0);
-              else acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tm][tn], 0, 0, 0);
-            }
-    } while (--ktiles > 0);
-    if (ABL == 5) {
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] += acc2[tm][tn];
-    }
-  } else {
-    pipelined_k_loop<AE, BE, ASZ, BSZ>(
-        ktiles, As, Bs, load_tile, store_tile, advance,
-        [&](const float* Asb, const float* Bsb) {
-          if (SPLIT) mfma_sweep_split<WM, WN, TM, TN>(Asb, Bsb, acc, wm, wn, lane);
-          else mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane);
-        });
-  }
-  if (ABL == 6) {                                    // keep the accumulators live with one store per lane
-    float t = 0.f;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[tm][tn][r];
-    if (t == 123.456f) prm.out[0] = t;
-    return;
-  }
+  pipelined_k_loop<AE, BE, ASZ, BSZ>(
+      ktiles, As, Bs, load_tile, store_tile, advance,
+      [&](const float* Asb, const float* Bsb) {
+        if (SPLIT) mfma_sweep_split<WM, WN, TM, TN>(Asb, Bsb, acc, wm, wn, lane);
+        else mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane);
+      });
+  if (dbg_on) t_loop_end = __builtin_amdgcn_s_memtime();
   igemm_epilogue<WM, WN, TM, TN>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
+  if (dbg_on) {
+    __builtin_amdgcn_s_waitcnt(0);                 // include the drain of this wave's stores
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    prm.dbg[3 * dbg_lin + 0] = t_start;
+    prm.dbg[3 * dbg_lin + 1] = t_loop_end;
+    prm.dbg[3 * dbg_lin + 2] = t_end;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -940,7 +857,6 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     gp += BK * N;
   };
   const int ktiles = (rend - rbeg + BK - 1) / BK;
-  stagger_first_round(ktiles, TM * TN * (BK / 2), prm.blocks_per_cu, prm.stagger);
   pipelined_k_loop<AE, BE, BK * LDA, BK * LDB>(
       ktiles, As, Bs, load_tile, store_tile, advance,
       [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
@@ -1006,12 +922,6 @@ int precision_mode() {
 }
 void set_precision_mode(int m) { g_precision = m ? 1 : 0; }
 
-static int stagger_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("LIP_STAGGER"); v = e ? atoi(e) : 0; }   // measured: no gain (r11) -> off
-  return v;
-}
-
 static bool igemm_fast_ok(const IgemmP& p) {
   for (int s = 0; s < p.nseg; ++s) {
     const SegP& q = p.seg[s];
@@ -1027,30 +937,38 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
   const long long tiles = (long long)((p.R + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
   dim3 grid((unsigned)tiles, (unsigned)P, 1);
   static const bool force_generic = getenv("LIP_GENERIC") != nullptr;     // A/B switch
-  static const int abl = getenv("LIP_ABLATE") ? atoi(getenv("LIP_ABLATE")) : 0;  // timing experiments
   if (!force_generic && igemm_fast_ok(p)) {
-    static int bpc = 0;
-    if (bpc == 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, igemm_fast_kernel<WM, WN, TM, TN, 0>, T::NT, 0) != hipSuccess || bpc < 1) bpc = 1;
-    }
     IgemmP q = p;
-    static const bool nored = getenv("LIP_NORED") != nullptr;      // timing experiment: drop the reductions
-    if (nored) { q.red0 = nullptr; q.red1 = nullptr; }
     q.zeros = zero_page();
     if (!q.zeros) return hipErrorOutOfMemory;
-    q.blocks_per_cu = bpc;
-    q.stagger = stagger_enabled();
-    static const int xcd = getenv("LIP_XCD") ? atoi(getenv("LIP_XCD")) : 0;   // measured r24: no gain -> off
-    q.xcd_remap = xcd;
-    if (abl == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 1>), grid, dim3(T::NT), 0, st, q);
-    else if (abl == 2) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 2>), grid, dim3(T::NT), 0, st, q);
-    else if (abl == 3) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 3>), grid, dim3(T::NT), 0, st, q);
-    else if (abl == 4) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 4>), grid, dim3(T::NT), 0, st, q);
-    else if (abl == 5) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 5>), grid, dim3(T::NT), 0, st, q);
-    else if (abl == 6) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 6>), grid, dim3(T::NT), 0, st, q);
-    else if (abl == 7) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 7>), grid, dim3(T::NT), 0, st, q);
-    else if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, 0, true>), grid, dim3(T::NT), 0, st, q);
-    else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q);
+    static const bool dbg = getenv("LIP_DBG") != nullptr;       // diagnostic stamps (never in a timed run)
+    static unsigned long long* dbgbuf = nullptr;
+    q.dbg = nullptr;
+    if (dbg) {
+      if (!dbgbuf && hipMalloc((void**)&dbgbuf, 3 * 8192 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+      (void)hipMemsetAsync(dbgbuf, 0, 3 * 8192 * sizeof(unsigned long long), st);
+      q.dbg = dbgbuf;
+    }
+    if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
+    else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false>), grid, dim3(T::NT), 0, st, q);
+    if (dbg) {
+      static int reports = 0;
+      if (reports < 60) {
+        (void)hipStreamSynchronize(st);
+        static unsigned long long host[3 * 8192];
+        (void)hipMemcpy(host, dbgbuf, sizeof(host), hipMemcpyDeviceToHost);
+        const long long nb = (long long)tiles * P < 8192 ? (long long)tiles * P : 8192;
+        double loop = 0, epi = 0; long long cnt = 0;
+        for (long long b = 0; b < nb; ++b) {
+          if (!host[3 * b + 2]) continue;
+          loop += (double)(host[3 * b + 1] - host[3 * b]); epi += (double)(host[3 * b + 2] - host[3 * b + 1]);
+          ++cnt;
+        }
+        if (cnt) fprintf(stderr, "[lip dbg] igemm<%d,%d,%d,%d> split=%d blocks=%lld (of %lld) nseg=%d N=%d: K-loop %.0f cycles, epilogue+drain %.0f cycles per block\n",
+                         WM, WN, TM, TN, precision_mode(), cnt, (long long)tiles * P, p.nseg, p.N, loop / cnt, epi / cnt);
+        ++reports;
+      }
+    }
   }
   else
     hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
@@ -1078,15 +996,9 @@ static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
   dim3 grid((unsigned)tiles, (unsigned)P, (unsigned)p.ksplit);
   static const bool force_generic = getenv("LIP_GENERIC") != nullptr;     // A/B switch
   if (!force_generic && (p.C & 3) == 0 && (((uintptr_t)p.a) & 15) == 0) {
-    static int bpc = 0;
-    if (bpc == 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, wgrad_fast_kernel<WM, WN, TM, TN>, T::NT, 0) != hipSuccess || bpc < 1) bpc = 1;
-    }
     WgradP q = p;
     q.zeros = zero_page();
     if (!q.zeros) return hipErrorOutOfMemory;
-    q.blocks_per_cu = bpc;
-    q.stagger = (p.ksplit == 1) ? stagger_enabled() : 0;
     hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q);
   }
   else
