@@ -62,6 +62,8 @@ enum {
   LIP_OP_PRIMAL_POST = 6, /* z -> xhat, y, a = act(y), dphi = act'(y)   (primal pass, once per binding)  */
   LIP_OP_SOFTMAX = 7,     /* logits -> p, sqrt(p)                        (primal pass)                   */
   LIP_OP_HEAD = 8,        /* output-space Hessian / square-root factor action  src/ggn.py:16-39,125-131  */
+  /* window pools: with a NONE aux0 ref the three ops below compute the window AVERAGE (sum / (KH*KW), padding
+     counted -- flax.linen.avg_pool, used by the reference's LeNet5 src/scalemodels.py:28,34) and its transpose */
   LIP_OP_MAXPOOL_PRIMAL = 9,  /* max pool of the primal activations + cached argmax (aux0)             */
   LIP_OP_MAXPOOL_FWD = 10,    /* tangent of max pool: gather at the cached argmax                      */
   LIP_OP_MAXPOOL_BWD = 11     /* cotangent of max pool (gather over the covering windows), times dphi,

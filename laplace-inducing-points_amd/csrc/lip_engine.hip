@@ -196,7 +196,7 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       p.xhat = resolve(c, op.xhat2);
       p.red0 = resolve(c, op.red0); p.red0_ps = op.red0.pstride;
       p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
-      if (!p.in || !p.out || !p.amax || p.C <= 0 || p.C > 8192 || p.stride <= 0 || (p.red1 && !p.xhat)) { set_error("MAXPOOL: bad operands"); return LIP_ERR_ARG; }
+      if (!p.in || !p.out || p.C <= 0 || p.C > 8192 || p.stride <= 0 || (p.red1 && !p.xhat)) { set_error("MAXPOOL: bad operands"); return LIP_ERR_ARG; }
       if (op.kind == LIP_OP_MAXPOOL_PRIMAL) RUN_CHECK(launch_maxpool_primal(p, c.st), "maxpool_primal launch");
       else if (op.kind == LIP_OP_MAXPOOL_FWD) RUN_CHECK(launch_maxpool_fwd(p, c.P, c.st), "maxpool_fwd launch");
       else RUN_CHECK(launch_maxpool_bwd(p, c.P, c.st), "maxpool_bwd launch");

@@ -118,7 +118,8 @@ hipError_t launch_pool_bwd(const PoolP& p, int P, hipStream_t st) {
   return hipGetLastError();
 }
 
-// ---- max pool --------------------------------------------------------------------------------------------------
+// ---- window pools (max / average) ----------------------------------------------------------------------------
+// A null argmax buffer selects the window AVERAGE (sum / (KH*KW), padding counted: flax.linen.avg_pool's default).
 // primal: out = max over the window, argmax cached as the linear pixel index of the winning input (first max wins)
 __global__ __launch_bounds__(256) void maxpool_primal_kernel(const MaxPoolP prm) {
   const long long total = (long long)prm.n * prm.OH * prm.OW * prm.C;
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(256) void maxpool_primal_kernel(const MaxPoolP prm)
     const int ow = (int)(t % prm.OW); t /= prm.OW;
     const int oh = (int)(t % prm.OH);
     const int i = (int)(t / prm.OH);
-    float best = -3.0e38f; int bi = -1;
+    const bool avg = prm.amax_w == nullptr;
+    float best = avg ? 0.f : -3.0e38f; int bi = -1;
     for (int kh = 0; kh < prm.KH; ++kh) {
       const int ih = oh * prm.stride + kh - prm.pad_h;
       if (ih < 0 || ih >= prm.IH) continue;
@@ -136,9 +138,11 @@ __global__ __launch_bounds__(256) void maxpool_primal_kernel(const MaxPoolP prm)
         const int iw = ow * prm.stride + kw - prm.pad_w;
         if (iw < 0 || iw >= prm.IW) continue;
         const float v = prm.in[(((long long)i * prm.IH + ih) * prm.IW + iw) * prm.C + c];
-        if (v > best) { best = v; bi = ih * prm.IW + iw; }
+        if (avg) best += v;
+        else if (v > best) { best = v; bi = ih * prm.IW + iw; }
       }
     }
+    if (avg) { prm.out[idx] = best * (1.f / (float)(prm.KH * prm.KW)); continue; }
     prm.out[idx] = best;
     prm.amax_w[idx] = (float)bi;
   }
@@ -161,6 +165,22 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const MaxPoolP prm) {
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int c = (int)(idx % prm.C);
     const long long i = idx / per_img_out;
+    if (!prm.amax) {
+      long long t = (idx % per_img_out) / prm.C;
+      const int ow = (int)(t % prm.OW), oh = (int)(t / prm.OW);
+      float acc = 0.f;
+      for (int kh = 0; kh < prm.KH; ++kh) {
+        const int ih = oh * prm.stride + kh - prm.pad_h;
+        if (ih < 0 || ih >= prm.IH) continue;
+        for (int kw = 0; kw < prm.KW; ++kw) {
+          const int iw = ow * prm.stride + kw - prm.pad_w;
+          if (iw < 0 || iw >= prm.IW) continue;
+          acc += in[i * per_img_in + ((long long)ih * prm.IW + iw) * prm.C + c];
+        }
+      }
+      out[idx] = acc * (1.f / (float)(prm.KH * prm.KW));
+      continue;
+    }
     const int pix = (int)prm.amax[idx];
     out[idx] = pix >= 0 ? in[i * per_img_in + (long long)pix * prm.C + c] : 0.f;
   }
@@ -207,9 +227,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const MaxPoolP prm) {
         const int ow = tw / prm.stride;
         if (ow >= prm.OW) continue;
         const long long o = i * per_img_g + ((long long)oh * prm.OW + ow) * C + c;
-        if (prm.amax[o] == me) v += g[o];
+        if (!prm.amax || prm.amax[o] == me) v += g[o];
       }
     }
+    if (!prm.amax) v *= 1.f / (float)(prm.KH * prm.KW);
     if (prm.dphi) v *= prm.dphi[idx];
     out[idx] = v;
     if (red) {

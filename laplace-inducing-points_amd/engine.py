@@ -113,6 +113,8 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
         a_off[u.dst] = palloc(n * h * w * c)
         if u.kind == "maxpool":
             amax_off[u.dst] = palloc(n * h * w * c)
+        if u.kind == "avgpool":
+            amax_off[u.dst] = None             # a NONE argmax ref selects the window average (include/lip.h)
         if u.kind == "conv":
             zmax = max(zmax, n * h * w * c)
             if u.act != "none":
@@ -159,6 +161,9 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
         ih, iw, _ = tens[u.src]
         return dict(IH=ih, IW=iw, Cc=u.cin, KH=u.kh, KW=u.kw, stride=u.stride, pad_h=u.pad_h, pad_w=u.pad_w)
 
+    def AMAX(t):
+        return NONE if amax_off[t] is None else P(amax_off[t])
+
     def pool_seg(u: Unit, a_ref):
         ih, iw, cc = tens[u.src]
         return _seg(a_ref, NONE, ih, iw, cc, u.kh, u.kw, u.stride, u.pad_h, u.pad_w, 0)
@@ -174,9 +179,9 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
             primal.append(SymOp(nv.OP_POOL_FWD, dict(n_img=n, OH=ih, OW=iw, N=c, fscale=1.0 / (ih * iw)),
                                 dict(out=P(a_off[u.dst])), [dict(a=P(a_off[u.src]), b=NONE)]))
             continue
-        if u.kind == "maxpool":
+        if u.kind in ("maxpool", "avgpool"):
             primal.append(SymOp(nv.OP_MAXPOOL_PRIMAL, dict(n_img=n, OH=oh, OW=ow, N=c),
-                                dict(out=P(a_off[u.dst]), aux0=P(amax_off[u.dst])), [pool_seg(u, P(a_off[u.src]))]))
+                                dict(out=P(a_off[u.dst]), aux0=AMAX(u.dst)), [pool_seg(u, P(a_off[u.src]))]))
             continue
         g = geom(u)
         primal.append(SymOp(nv.OP_IGEMM, dict(n_img=n, OH=oh, OW=ow, N=c), dict(out=P(z_off)),
@@ -222,9 +227,9 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
                                  dict(out=W(out)), [dict(a=W(da[u.src]), b=NONE)]))
             da[u.dst] = out
             continue
-        if u.kind == "maxpool":
+        if u.kind in ("maxpool", "avgpool"):
             tangent.append(SymOp(nv.OP_MAXPOOL_FWD, dict(n_img=n, OH=oh, OW=ow, N=c),
-                                 dict(out=W(out), aux0=P(amax_off[u.dst])), [pool_seg(u, W(da[u.src]))]))
+                                 dict(out=W(out), aux0=AMAX(u.dst)), [pool_seg(u, W(da[u.src]))]))
             da[u.dst] = out
             continue
         g = geom(u)
@@ -291,7 +296,7 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
             conv_c = [cu for cu, role in cons if role == "src" and cu.kind == "conv"]
             res_c = [cu for cu, role in cons if role == "res"]
             pool_c = [cu for cu, role in cons if role == "src" and cu.kind == "meanpool"]
-            mpool_c = [cu for cu, role in cons if role == "src" and cu.kind == "maxpool"]
+            mpool_c = [cu for cu, role in cons if role == "src" and cu.kind in ("maxpool", "avgpool")]
             view_c = [cu for cu, role in cons if cu.kind == "view"]
             if view_c:
                 raise NotImplementedError("flatten of a non-input tensor is not supported by the HIP engine yet")
@@ -302,7 +307,7 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
                 mu = mpool_c[0]
                 moh, mow, _ = tens[mu.dst]
                 out = VT(tsize(t), f"g{t}")
-                refs = dict(out=W(out), aux0=P(amax_off[mu.dst]), **reds)
+                refs = dict(out=W(out), aux0=AMAX(mu.dst), **reds)
                 if t in dphi_off:
                     refs["dphi"] = P(dphi_off[t])
                 backward.append(SymOp(nv.OP_MAXPOOL_BWD, dict(n_img=n, OH=moh, OW=mow, N=c), refs,
@@ -535,7 +540,7 @@ class LinearizedNet:
         self.consts = build_consts(cn, state.params, state.batch_stats, self.device)
         self.prim = torch.zeros(cn.prim_floats, **f32)
         nin = self.n * net.tensors[0][0] * net.tensors[0][1] * net.tensors[0][2]
-        self.prim[cn.input_off:cn.input_off + nin] = Z.detach().to(**f32).reshape(-1)
+        self.prim[cn.input_off:cn.input_off + nin] = net.prepare_input(Z.detach().to(**f32)).reshape(-1)
         chunk = int(max(1, min(max_chunk, workspace_bytes // (4 * cn.work_pp))))
         self.chunk = chunk
         self.work = torch.empty(cn.work_pp * chunk, **f32)

@@ -56,7 +56,7 @@ def _same_pad(n_in: int, k: int, stride: int) -> Tuple[int, int]:
 
 @dataclasses.dataclass
 class Unit:
-    kind: str                       # 'conv' | 'meanpool'
+    kind: str                       # 'conv' | 'meanpool' | 'maxpool' | 'avgpool' | 'view'
     src: int
     dst: int
     kh: int = 1
@@ -75,6 +75,7 @@ class Unit:
     bn_eps: float = 1e-5
     res: Optional[int] = None       # tensor id added before the activation
     act: str = "none"
+    flat_kernel: bool = False       # Dense on a flattened (H,W,C) tensor: kernel stored as (H*W*C, out)
 
 
 def _get(tree, path):
@@ -86,13 +87,18 @@ def _get(tree, path):
 class NetSpec:
     """A straight-line program over NHWC tensors; tensor 0 is the input."""
 
-    def __init__(self, input_shape: Sequence[int], param_root: Path = ("params",)):
+    def __init__(self, input_shape: Sequence[int], param_root: Path = ("params",), tile_channels: int = 1):
         ishape = tuple(int(s) for s in input_shape)
         self.input_shape_raw = ishape
         if len(ishape) == 1:
             ishape = (1, 1, ishape[0])
         elif len(ishape) == 2:
             ishape = (ishape[0], ishape[1], 1)
+        # ``jnp.tile(x, (1,1,1,3))`` of a grayscale input (reference src/scalemodels.py:127-128): tensor 0 is the
+        # tiled image; ``prepare_input`` does the replication (the input carries no tangent, so this is host-side)
+        self.tile_channels = int(tile_channels)
+        if self.tile_channels > 1:
+            ishape = (ishape[0], ishape[1], ishape[2] * self.tile_channels)
         self.tensors: List[Tuple[int, int, int]] = [ishape]
         self.units: List[Unit] = []
         self.param_root = tuple(param_root)
@@ -114,10 +120,18 @@ class NetSpec:
 
     def dense(self, src: int, name: str, features: int, act: str = "none",
               scope: Path = ()) -> int:
+        p = self.param_root + tuple(scope) + (name,)
+        h, w, c = self.tensors[src]
+        dst = self._new((1, 1, features))
+        if src != 0 and h * w > 1:
+            # Dense on a flattened feature map == an (h x w) VALID convolution whose HWIO kernel, raveled, is the
+            # (h*w*c, features) Dense kernel (NHWC flatten order) -- no copy, no view op on the device
+            self.units.append(Unit("conv", src, dst, h, w, 1, 0, 0, c, features,
+                                   kernel=p + ("kernel",), bias=p + ("bias",), act=act, flat_kernel=True))
+            self.out = dst
+            return dst
         src = self.flatten(src)
         cin = self.tensors[src][2]
-        dst = self._new((1, 1, features))
-        p = self.param_root + tuple(scope) + (name,)
         self.units.append(Unit("conv", src, dst, 1, 1, 1, 0, 0, cin, features,
                                kernel=p + ("kernel",), bias=p + ("bias",), act=act))
         self.out = dst
@@ -167,12 +181,29 @@ class NetSpec:
         self.out = dst
         return dst
 
+    def avgpool(self, src: int, k: int = 2, stride: int = 2, padding="VALID") -> int:
+        """``nn.avg_pool`` (window k x k, sum / k^2 with padding counted -- Flax's default)."""
+        h, w, c = self.tensors[src]
+        oh, ph = self._out_and_pad(h, k, stride, padding)
+        ow, pw = self._out_and_pad(w, k, stride, padding)
+        dst = self._new((oh, ow, c))
+        self.units.append(Unit("avgpool", src, dst, k, k, stride, ph, pw, c, c))
+        self.out = dst
+        return dst
+
     def meanpool(self, src: int) -> int:
         h, w, c = self.tensors[src]
         dst = self._new((1, 1, c))
         self.units.append(Unit("meanpool", src, dst, cin=c, cout=c))
         self.out = dst
         return dst
+
+    def prepare_input(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, *input_shape) -> (B, H, W, C) of tensor 0 (reshape + channel tiling)."""
+        h, w, c = self.tensors[0]
+        t = self.tile_channels
+        xb = x.reshape(-1, h, w, c // t)
+        return xb.repeat(1, 1, 1, t) if t > 1 else xb
 
     # ------------------------------------------------------------- properties
     @property
@@ -207,7 +238,7 @@ class NetSpec:
                 continue
             fan_in = u.kh * u.kw * u.cin
             shape = (u.cin, u.cout) if (u.kh == 1 and u.kw == 1 and self._is_dense(u)) \
-                else (u.kh, u.kw, u.cin, u.cout)
+                else (u.kh * u.kw * u.cin, u.cout) if u.flat_kernel else (u.kh, u.kw, u.cin, u.cout)
             put(params, u.kernel, torch.randn(shape, generator=g, dtype=torch.float64) / math.sqrt(fan_in))
             if u.bias is not None:
                 put(params, u.bias, 0.1 * torch.randn(u.cout, generator=g, dtype=torch.float64))
@@ -239,10 +270,10 @@ class NetSpec:
         raw = self.input_shape_raw
         if tuple(x.shape) == raw:
             single = True
-            xb = x.reshape((1,) + self.tensors[0])
+            xb = self.prepare_input(x[None])
         else:
             single = False
-            xb = x.reshape((x.shape[0],) + self.tensors[0])
+            xb = self.prepare_input(x)
         vals: Dict[int, torch.Tensor] = {0: xb}
         for u in self.units:
             a = vals[u.src]
@@ -260,8 +291,18 @@ class NetSpec:
                 an = F.pad(a.permute(0, 3, 1, 2), (u.pad_w, hi_w, u.pad_h, hi_h), value=float("-inf"))
                 vals[u.dst] = F.max_pool2d(an, (u.kh, u.kw), stride=u.stride).permute(0, 2, 3, 1)
                 continue
+            if u.kind == "avgpool":
+                oh, ow, _ = self.tensors[u.dst]
+                h, w = a.shape[1], a.shape[2]
+                hi_h = max((oh - 1) * u.stride + u.kh - h - u.pad_h, 0)
+                hi_w = max((ow - 1) * u.stride + u.kw - w - u.pad_w, 0)
+                an = F.pad(a.permute(0, 3, 1, 2), (u.pad_w, hi_w, u.pad_h, hi_h))
+                vals[u.dst] = F.avg_pool2d(an, (u.kh, u.kw), stride=u.stride).permute(0, 2, 3, 1)
+                continue
             W = _get(params, u.kernel)
-            if u.kh == 1 and u.kw == 1 and u.stride == 1:
+            if u.flat_kernel:
+                z = (a.reshape(a.shape[0], -1) @ W).reshape(a.shape[0], 1, 1, u.cout)
+            elif u.kh == 1 and u.kw == 1 and u.stride == 1:
                 z = a @ W.reshape(u.cin, u.cout)
             elif u.kh == 1 and u.kw == 1:
                 z = a[:, ::u.stride, ::u.stride, :] @ W.reshape(u.cin, u.cout)

@@ -26,6 +26,22 @@ def LargeClassifier(input_shape: Sequence[int], numh: Sequence[int], numl: int, 
     return net
 
 
+def LeNet5(num_classes: int = 10, input_shape: Sequence[int] = (28, 28, 1)) -> NetSpec:
+    """``src/scalemodels.py:11-49``: zero-pad 2 + 5x5 VALID conv(6) (== 5x5 conv with padding 2) -> ReLU -> 2x2 avg
+    pool -> 5x5 VALID conv(16) -> ReLU -> 2x2 avg pool -> flatten(400) -> Dense(120) -> ReLU -> Dense(84) -> ReLU ->
+    Dense(10); convolutions carry a bias (Flax default).  61 706 parameters."""
+    net = NetSpec(tuple(input_shape))
+    x = net.conv(0, "Conv_0", 6, 5, 1, padding=2, act="relu", use_bias=True)
+    x = net.avgpool(x, 2, 2)
+    x = net.conv(x, "Conv_1", 16, 5, 1, padding="VALID", act="relu", use_bias=True)
+    x = net.avgpool(x, 2, 2)
+    x = net.dense(x, "Dense_0", 120, act="relu")
+    x = net.dense(x, "Dense_1", 84, act="relu")
+    net.dense(x, "Dense_2", num_classes)
+    net.model_type = "classifier"
+    return net
+
+
 def _basic_block(net: NetSpec, x: int, scope: str, channels: int, stride: int) -> int:
     sc = (scope,)
     h = net.conv(x, "Conv_0", channels, 3, stride, bn="BatchNorm_0", act="relu", scope=sc)
@@ -39,7 +55,10 @@ def _basic_block(net: NetSpec, x: int, scope: str, channels: int, stride: int) -
 
 def ResNet1M(num_classes: int, input_shape: Sequence[int] = (32, 32, 3),
              widths: Sequence[int] = (32, 64, 128), blocks_per_stage: int = 3) -> NetSpec:
-    net = NetSpec(tuple(input_shape))
+    ishape = tuple(input_shape)
+    # grayscale input is replicated to 3 channels (``src/scalemodels.py:127-128``)
+    gray = (len(ishape) == 2) or (len(ishape) == 3 and ishape[2] == 1)
+    net = NetSpec(ishape, tile_channels=3 if gray else 1)
     x = net.conv(0, "Conv_0", widths[0], 3, 1, bn="BatchNorm_0", act="relu")
     b = 0
     for si, ch in enumerate(widths):
@@ -87,8 +106,11 @@ def ResNet50(num_classes: int = 1000, input_shape: Sequence[int] = (224, 224, 3)
 
 
 def get_model(model_cfg) -> NetSpec:
-    """Reference ``src/scalemodels.py:166-186`` (LeNet5 is not on the hot-path configs)."""
+    """Reference ``src/scalemodels.py:166-186``; ``input_shape`` may be given for ResNet1 (the reference infers it
+    from the data: grayscale inputs are tiled to 3 channels)."""
     name = model_cfg["name"]
+    if name == "LeNet5":
+        return LeNet5()
     if name == "large_classifier":
         return LargeClassifier(tuple(model_cfg["input_shape"]), model_cfg["num_h"],
                                model_cfg["num_l"], model_cfg.get("num_c"))
@@ -96,5 +118,5 @@ def get_model(model_cfg) -> NetSpec:
         from .toymodels import SimpleClassifier
         return SimpleClassifier(model_cfg["num_h"], model_cfg["num_l"], model_cfg.get("num_c"))
     if name == "ResNet1":
-        return ResNet1M(model_cfg.get("num_c"))
+        return ResNet1M(model_cfg.get("num_c"), input_shape=tuple(model_cfg.get("input_shape", (32, 32, 3))))
     raise ValueError(f"Unknown model name: {name}")

@@ -114,3 +114,27 @@ class TrainState:
         f = lambda t: torch.as_tensor(t).to(device=device, dtype=dtype)
         return self.replace(params=tree_map(f, self.params),
                             batch_stats=tree_map(f, self.batch_stats))
+
+
+def save_array_checkpoint(array, ckpt_dir, name, step):
+    """Reference ``src/utils.py:20`` (implemented in ``checkpoint.py``)."""
+    from .checkpoint import save_array_checkpoint as f
+    return f(array, ckpt_dir, name, step)
+
+
+def load_array_checkpoint(ckpt_dir, name, step, device=None):
+    """Reference ``src/utils.py:33``."""
+    from .checkpoint import load_array_checkpoint as f
+    return f(ckpt_dir, name, step, device=device)
+
+
+def save_checkpoint(train_state, ckpt_dir, prefix, step):
+    """Reference ``src/utils.py:46``."""
+    from .checkpoint import save_checkpoint as f
+    return f(train_state, ckpt_dir, prefix, step)
+
+
+def load_checkpoint(ckpt_dir, prefix, target=None, **kw):
+    """Reference ``src/utils.py:63``."""
+    from .checkpoint import load_checkpoint as f
+    return f(ckpt_dir, prefix, target=target, **kw)

@@ -12,7 +12,7 @@ if _root not in _sys.path:
 import lip_amd as _pkg  # noqa: E402
 
 __path__ = list(_pkg.__path__)
-for _m in ("utils", "netspec", "toymodels", "scalemodels", "ggn", "lla", "sample", "stochtrace", "krylov", "train_alpha", "evaluate", "train_inducing"):
+for _m in ("utils", "netspec", "toymodels", "scalemodels", "ggn", "lla", "sample", "stochtrace", "krylov", "train_alpha", "evaluate", "train_inducing", "checkpoint"):
     _mod = _il.import_module("lip_amd." + _m)
     _sys.modules["src." + _m] = _mod
     globals()[_m] = _mod

@@ -18,8 +18,8 @@ class TapeMachine:
         self.theta = theta.to(F64).reshape(-1)
         self.consts = consts.to(F64).reshape(-1)
         self.prim = torch.zeros(cn.prim_floats, dtype=F64)
-        nin = Z.numel()
-        self.prim[cn.input_off:cn.input_off + nin] = Z.to(F64).reshape(-1)
+        zin = cn.net.prepare_input(Z.to(F64)).reshape(-1)
+        self.prim[cn.input_off:cn.input_off + zin.numel()] = zin
         self.work = torch.zeros(cn.work_pp * chunk, dtype=F64)
         self.V = self.Y = self.H = None
 
@@ -139,9 +139,33 @@ class TapeMachine:
         g = op.seg[0]
         return op.n_img, g.IH, g.IW, op.OH, op.OW, op.N, g.KH, g.KW, g.stride, g.pad_h, g.pad_w
 
+    def _avgpool(self, op, x, transpose=False):
+        """window average (NONE argmax ref): x (B, n, IH, IW, C) -> (B, n, OH, OW, C), or its transpose."""
+        n, IH, IW, OH, OW, Cc, KH, KW, st, ph, pw = self._maxpool_geom(op)
+        B = x.shape[0]
+        out = torch.zeros((B, n, IH, IW, Cc) if transpose else (B, n, OH, OW, Cc), dtype=F64)
+        for kh in range(KH):
+            for kw in range(KW):
+                for oh in range(OH):
+                    ih = oh * st + kh - ph
+                    if ih < 0 or ih >= IH:
+                        continue
+                    for ow in range(OW):
+                        iw = ow * st + kw - pw
+                        if iw < 0 or iw >= IW:
+                            continue
+                        if transpose:
+                            out[:, :, ih, iw, :] += x[:, :, oh, ow, :]
+                        else:
+                            out[:, :, oh, ow, :] += x[:, :, ih, iw, :]
+        return out / (KH * KW)
+
     def maxpool_primal(self, op):
         n, IH, IW, OH, OW, Cc, KH, KW, st, ph, pw = self._maxpool_geom(op)
         x = self.view(op.seg[0].a, 1, n * IH * IW * Cc).reshape(n, IH, IW, Cc)
+        if op.aux0.space == nv.SP_NONE:
+            self.view(op.out, 1, n * OH * OW * Cc).copy_(self._avgpool(op, x[None]).reshape(1, -1))
+            return
         out = torch.full((n, OH, OW, Cc), -3.0e38, dtype=F64)
         am = torch.full((n, OH, OW, Cc), -1.0, dtype=F64)
         for kh in range(KH):
@@ -163,6 +187,10 @@ class TapeMachine:
 
     def maxpool_fwd(self, op, P):
         n, IH, IW, OH, OW, Cc, KH, KW, st, ph, pw = self._maxpool_geom(op)
+        if op.aux0.space == nv.SP_NONE:
+            x = self.view(op.seg[0].a, P, n * IH * IW * Cc).reshape(P, n, IH, IW, Cc)
+            self.view(op.out, P, n * OH * OW * Cc).copy_(self._avgpool(op, x).reshape(P, -1))
+            return
         x = self.view(op.seg[0].a, P, n * IH * IW * Cc).reshape(P, n, IH * IW, Cc)
         am = self.view(op.aux0, 1, n * OH * OW * Cc).reshape(n, OH * OW, Cc).long()
         idx = am.clamp_min(0).unsqueeze(0).expand(P, -1, -1, -1)
@@ -172,10 +200,13 @@ class TapeMachine:
     def maxpool_bwd(self, op, P):
         n, IH, IW, OH, OW, Cc, KH, KW, st, ph, pw = self._maxpool_geom(op)
         g = self.view(op.seg[0].a, P, n * OH * OW * Cc).reshape(P, n, OH * OW, Cc)
-        am = self.view(op.aux0, 1, n * OH * OW * Cc).reshape(n, OH * OW, Cc).long()
-        out = torch.zeros(P, n, IH * IW, Cc, dtype=F64)
-        idx = am.clamp_min(0).unsqueeze(0).expand(P, -1, -1, -1)
-        out.scatter_add_(2, idx, g * (am >= 0).unsqueeze(0))
+        if op.aux0.space == nv.SP_NONE:
+            out = self._avgpool(op, g.reshape(P, n, OH, OW, Cc), transpose=True)
+        else:
+            am = self.view(op.aux0, 1, n * OH * OW * Cc).reshape(n, OH * OW, Cc).long()
+            out = torch.zeros(P, n, IH * IW, Cc, dtype=F64)
+            idx = am.clamp_min(0).unsqueeze(0).expand(P, -1, -1, -1)
+            out.scatter_add_(2, idx, g * (am >= 0).unsqueeze(0))
         v = out.reshape(P, n * IH * IW, Cc)
         if op.dphi.space != nv.SP_NONE:
             v = v * self.view(op.dphi, 1, n * IH * IW * Cc).reshape(1, n * IH * IW, Cc)

@@ -11,7 +11,7 @@ import torch
 
 from lip_amd import _native as nv
 from lip_amd.engine import LinearizedNet, build_consts
-from lip_amd.scalemodels import LargeClassifier, ResNet1M, ResNet50
+from lip_amd.scalemodels import LargeClassifier, LeNet5, ResNet1M, ResNet50
 from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
 from lip_amd.utils import flatten_nn_params
 from tape_emulator import TapeMachine
@@ -37,6 +37,9 @@ def _cases():
                           torch.rand(2, 20, 20, 3, dtype=F64, generator=g), "classifier", 2),
         "resnet50_small": (ResNet50(100, input_shape=(32, 32, 3), stem=16, widths=(16, 32), blocks=(1, 1)),
                            torch.rand(3, 32, 32, 3, dtype=F64, generator=g), "classifier", 2),
+        "lenet5": (LeNet5(10), torch.rand(7, 28, 28, 1, dtype=F64, generator=g), "classifier", 3),
+        "resnet_gray": (ResNet1M(3, input_shape=(12, 12, 1), widths=(8, 16), blocks_per_stage=1),
+                        torch.rand(4, 12, 12, 1, dtype=F64, generator=g), "classifier", 2),
     }
 
 

@@ -7,7 +7,7 @@ import torch
 
 from lip_amd import _native as nv
 from lip_amd.engine import build_consts, compile_net
-from lip_amd.scalemodels import LargeClassifier, ResNet1M, ResNet50
+from lip_amd.scalemodels import LargeClassifier, LeNet5, ResNet1M, ResNet50
 from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
 from lip_amd.utils import flatten_nn_params
 from oracle.ggn import compute_ggn_vp, compute_W_vps
@@ -23,6 +23,9 @@ CASES = {
                torch.rand(3, 8, 8, 3, dtype=F64, generator=G), "classifier", None),
     "resnet50_tiny": (ResNet50(6, input_shape=(20, 20, 3), stem=8, widths=(4, 8), blocks=(2, 1)),
                       torch.rand(2, 20, 20, 3, dtype=F64, generator=G), "classifier", 9),
+    "lenet5_small": (LeNet5(5, input_shape=(16, 16, 1)), torch.rand(2, 16, 16, 1, dtype=F64, generator=G), "classifier", 7),
+    "resnet_gray": (ResNet1M(3, input_shape=(8, 8, 1), widths=(4, 8), blocks_per_stage=1),
+                    torch.rand(3, 8, 8, 1, dtype=F64, generator=G), "classifier", None),
 }
 
 
@@ -78,3 +81,12 @@ def test_resnet50_parameter_count():
     st = create_state(net, 0)
     flat, _ = flatten_nn_params(st.params)
     assert flat.numel() == 25_557_032
+
+
+def test_lenet5_parameter_count():
+    """src/scalemodels.py:12 "~60 k parameters": 156 + 2416 + 48120 + 10164 + 850."""
+    net = LeNet5()
+    st = create_state(net, 0)
+    assert flatten_nn_params(st.params)[0].numel() == 61706
+    assert st.params["params"]["Dense_0"]["kernel"].shape == (400, 120)
+    assert st.apply_fn({"params": st.params["params"]}, torch.rand(3, 28, 28, 1)).shape == (3, 10)
