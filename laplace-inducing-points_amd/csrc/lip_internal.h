@@ -53,6 +53,10 @@ struct IgemmP {
   const float* xhat2;
   const float* zeros;                   // >= 16 floats of device zeros (masked gather rows)
   unsigned long long* dbg;              // diagnostic s_memtime stamps (null in every real run)
+  // parity-class row order of a stride-2 data gradient (fast kernel, OH and OW even): the rows of one block all
+  // share (oh & 1, ow & 1), so the taps whose parity cannot match are skipped instead of gathered as zeros
+  int Rc, OHW2, OW2;                    // rows per class n*(OH/2)*(OW/2), (OH/2)*(OW/2), OW/2
+  FastDiv dOHW2, dOW2;
 };
 
 struct WgradP {

@@ -175,12 +175,20 @@ __device__ __forceinline__ void pipelined_k_loop(int T, float* As, float* Bs, Lo
 // behind a store that might alias it, so a phase costs one memory round trip instead of eight.
 // Measured on MI355X and rejected (no gain, more VGPRs): software-pipelining the phases with two register sets,
 // and issuing phase 0's loads before the K loop.
-template <int WM, int WN, int TM, int TN>
+// PAR: the block's rows are class-local indices of the parity class (ph, pw) (see IgemmP); `row_of` maps them back
+// to rows of the output tensor.
+template <int WM, int WN, int TM, int TN, bool PAR = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[TM][TN], float* redbuf, int p, int r0,
-                                               int n0, int wm, int wn, int lane, int tid) {
+                                               int n0, int wm, int wn, int lane, int tid, int ph = 0, int pw = 0) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BN = T::BN;
-  const int N = prm.N, R = prm.R;
+  const int N = prm.N, R = PAR ? prm.Rc : prm.R;
+  auto row_of = [&](int r) -> int {
+    if (!PAR) return r;
+    const int i = prm.dOHW2.div(r), rem = r - i * prm.OHW2;
+    const int a = prm.dOW2.div(rem), b = rem - a * prm.OW2;
+    return i * prm.OHW + (2 * a + ph) * prm.OW + 2 * b + pw;
+  };
   const int l31 = lane & 31, lh = lane >> 5;
   const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
   const float* __restrict__ xhat = prm.xhat;
@@ -209,7 +217,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
           const int reg = 8 * h + q;
           const int r = rbase + (reg & 3) + 8 * (reg >> 2);
           const bool ok = cv && r < R;
-          const unsigned idx = ok ? (unsigned)(r * N + col) : 0u;     // clamped: loads stay unconditional
+          const unsigned idx = ok ? (unsigned)(row_of(r) * N + col) : 0u;     // clamped: loads stay unconditional
           xv[q] = has_e1 ? xhat[idx] : 0.f;
           rv[q] = res ? res[idx] : 0.f;
           dv[q] = dphi ? dphi[idx] : 1.f;
@@ -221,7 +229,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
           const int r = rbase + (reg & 3) + 8 * (reg >> 2);
           if (cv && r < R) {
             const float v = (acc[tm][tn][reg] * sc + e0v + e1v * xv[q] + rv[q]) * dv[q];
-            out[(unsigned)(r * N + col)] = v;
+            out[(unsigned)(row_of(r) * N + col)] = v;
             s0 += v;
             s1 += v * x2[q];
           }
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 //   once (branch-free, host-precomputed segment scalars) and reused for the C/16 K-tiles of the tap;
 //   B and LDS offsets are loop invariant.  ~8 non-MFMA instructions per MFMA instead of ~30.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool SPLIT = false>
+template <int WM, int WN, int TM, int TN, bool SPLIT = false, bool PAR = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
@@ -444,10 +452,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int N = prm.N, R = prm.R;
+  const int N = prm.N, R = PAR ? prm.Rc : prm.R;
   const int tiles_n = (N + BN - 1) / BN;
   const int bid = blockIdx.x;   // (an XCD-aware tile order was measured on MI355X: no gain — rejected)
-  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int tile_n = bid % tiles_n;
+  int tile_m = bid / tiles_n, ph = 0, pw = 0;
+  if (PAR) {                    // 4 parity classes x tiles-per-class row tiles
+    const int tpc = (prm.Rc + BM - 1) / BM, cls = tile_m / tpc;
+    tile_m -= cls * tpc; ph = cls >> 1; pw = cls & 1;
+  }
   const int p = blockIdx.y;
   const int r0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -468,8 +481,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   for (int j = 0; j < AQ; ++j) {
     const int r = r0 + ((tid + j * NT) >> 2);
     if (r < R) {
-      const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
-      vi[j] = i; voh[j] = prm.dOW.div(rem); vow[j] = rem - voh[j] * prm.OW;
+      if (PAR) {
+        const int i = prm.dOHW2.div(r), rem = r - i * prm.OHW2;
+        const int a = prm.dOW2.div(rem);
+        vi[j] = i; voh[j] = 2 * a + ph; vow[j] = 2 * (rem - a * prm.OW2) + pw;
+      } else {
+        const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
+        vi[j] = i; voh[j] = prm.dOW.div(rem); vow[j] = rem - voh[j] * prm.OW;
+      }
     } else {
       vi[j] = -1; voh[j] = 0; vow[j] = 0;
     }
@@ -493,14 +512,28 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   const float* abase = nullptr;
   const float* bbase = nullptr;
   int sIH = 0, sIW = 0, sC = 0, sKH = 0, sKW = 0, smul = 0, ssgn = 0, soffh = 0, soffw = 0, smask = 0, ssh = 0;
+  int kw0 = 0, kstep = 1;                 // PAR: first matching tap column and tap step of the segment
+  const float* bseg = nullptr;
 
+  // PAR: taps of a stride-2 transposed segment that can match the class: k = (parity + pad) & 1, step 2
+  auto first_tap = [&](const SegP& s, int par, int off) { return s.mask ? ((par + off) & 1) : 0; };
   auto begin_segment = [&]() {
+    if (PAR) {
+      while (seg < prm.nseg - 1 && (first_tap(prm.seg[seg], ph, prm.seg[seg].off_h) >= prm.seg[seg].KH ||
+                                    first_tap(prm.seg[seg], pw, prm.seg[seg].off_w) >= prm.seg[seg].KW)) ++seg;
+    }
     const SegP& s = prm.seg[seg];
     abase = s.a + (long long)p * s.a_ps;
     bbase = s.b + (long long)p * s.b_ps;
     sIH = s.IH; sIW = s.IW; sC = s.C; sKH = s.KH; sKW = s.KW;
     smul = s.mul; ssgn = s.sgn; soffh = s.off_h; soffw = s.off_w; smask = s.mask; ssh = s.sh;
     kh = 0; kw = 0; c0 = 0;
+    if (PAR) {
+      kstep = s.mask ? 2 : 1;
+      kh = first_tap(s, ph, s.off_h); kw0 = first_tap(s, pw, s.off_w); kw = kw0;
+      bseg = bbase;
+      bbase = bseg + (long long)((kh * sKW + kw) * sC) * N;
+    }
   };
   auto set_tap = [&]() {
     const int th = ssgn * kh + soffh, tw = ssgn * kw + soffw;      // scalar
@@ -562,28 +595,48 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
     bbase += BK * N;
     if (c0 == sC) {
       c0 = 0;
-      if (++kw == sKW) { kw = 0; ++kh; }
-      if (kh == sKH) { ++seg; begin_segment(); }
+      if (PAR) {
+        kw += kstep;
+        if (kw >= sKW) { kw = kw0; kh += kstep; }
+        if (kh >= sKH) { ++seg; begin_segment(); }
+        else bbase = bseg + (long long)((kh * sKW + kw) * sC) * N;
+      } else {
+        if (++kw == sKW) { kw = 0; ++kh; }
+        if (kh == sKH) { ++seg; begin_segment(); }
+      }
       set_tap();
     }
   };
 
   int ktiles = 0;
-  for (int q = 0; q < prm.nseg; ++q) ktiles += prm.seg[q].Ktot / BK;
+  for (int q = 0; q < prm.nseg; ++q) {
+    const SegP& s = prm.seg[q];
+    if (PAR) {
+      const int st = s.mask ? 2 : 1, h0 = first_tap(s, ph, s.off_h), w0 = first_tap(s, pw, s.off_w);
+      const int nh = h0 < s.KH ? (s.KH - h0 + st - 1) / st : 0, nw = w0 < s.KW ? (s.KW - w0 + st - 1) / st : 0;
+      ktiles += nh * nw * (s.C / BK);
+    } else {
+      ktiles += s.Ktot / BK;
+    }
+  }
   unsigned long long t_start = 0, t_loop_end = 0;
   const unsigned dbg_lin = blockIdx.x + blockIdx.y * gridDim.x;
   const bool dbg_on = prm.dbg != nullptr && dbg_lin < 8192 && tid == 0;
   if (dbg_on) t_start = __builtin_amdgcn_s_memtime();
-  begin_segment();
-  set_tap();
-  pipelined_k_loop<AE, BE, ASZ, BSZ>(
-      ktiles, As, Bs, load_tile, store_tile, advance,
-      [&](const float* Asb, const float* Bsb) {
-        if (SPLIT) mfma_sweep_split<WM, WN, TM, TN>(Asb, Bsb, acc, wm, wn, lane);
-        else mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane);
-      });
+  if (!PAR || ktiles > 0) {               // PAR: a class no tap can reach (lone 1x1 stride-2) is all zeros
+    begin_segment();
+    set_tap();
+    pipelined_k_loop<AE, BE, ASZ, BSZ>(
+        ktiles, As, Bs, load_tile, store_tile, advance,
+        [&](const float* Asb, const float* Bsb) {
+          if (SPLIT) mfma_sweep_split<WM, WN, TM, TN>(Asb, Bsb, acc, wm, wn, lane);
+          else mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane);
+        });
+  } else {
+    __syncthreads();                      // redbuf zeroing visible before the epilogue's atomics
+  }
   if (dbg_on) t_loop_end = __builtin_amdgcn_s_memtime();
-  igemm_epilogue<WM, WN, TM, TN>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
+  igemm_epilogue<WM, WN, TM, TN, PAR>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid, ph, pw);
   if (dbg_on) {
     __builtin_amdgcn_s_waitcnt(0);                 // include the drain of this wave's stores
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -949,7 +1002,23 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       (void)hipMemsetAsync(dbgbuf, 0, 3 * 8192 * sizeof(unsigned long long), st);
       q.dbg = dbgbuf;
     }
-    if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
+    // stride-2 data gradient on an even grid: parity-class row order, unreachable taps skipped (A/B: LIP_NOPAR)
+    static const bool nopar = getenv("LIP_NOPAR") != nullptr;
+    const int OH = p.OHW / p.OW;
+    bool par = !nopar && (OH % 2 == 0) && (p.OW % 2 == 0), any_s2 = false;
+    for (int s = 0; s < p.nseg; ++s) {
+      par = par && p.seg[s].mode == 1 && (p.seg[s].stride == 1 || p.seg[s].stride == 2);
+      any_s2 = any_s2 || (p.seg[s].mode == 1 && p.seg[s].stride == 2);
+    }
+    par = par && any_s2;
+    if (par) {
+      q.OW2 = p.OW / 2; q.OHW2 = (OH / 2) * q.OW2; q.Rc = (p.R / p.OHW) * q.OHW2;
+      q.dOHW2 = FastDiv((unsigned)q.OHW2); q.dOW2 = FastDiv((unsigned)q.OW2);
+      grid.x = (unsigned)(4ll * ((q.Rc + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN));
+      if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true, true>), grid, dim3(T::NT), 0, st, q);
+      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, true>), grid, dim3(T::NT), 0, st, q);
+    }
+    else if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
     else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false>), grid, dim3(T::NT), 0, st, q);
     if (dbg) {
       static int reports = 0;

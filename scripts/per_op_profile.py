@@ -1,0 +1,46 @@
+"""Per-op timing of the CIFAR ResNet1M sweep (each IGEMM / WGRAD op of the tangent and backward tapes timed alone
+with events through lip_debug_run_ops): which layer shapes sit furthest from the MFMA roof."""
+import sys, torch
+sys.path.insert(0, '.')
+import lip_amd
+from lip_amd import _native as nv, krylov
+from lip_amd.engine import LinearizedNet
+from lip_amd.scalemodels import ResNet1M
+from lip_amd.toymodels import create_state
+
+P = 256
+net = ResNet1M(10); st = create_state(net, seed=1, dtype=torch.float32)
+eng = LinearizedNet(st, torch.rand(50, 32, 32, 3).cuda(), "classifier", workspace_bytes=24 << 30, max_chunk=P)
+V = krylov.fill_rademacher(P, eng.D, 1, "cuda")
+Y = torch.zeros(P, eng.D, device="cuda"); H = torch.zeros(P, eng.n * eng.K, device="cuda")
+eng.ggn_vp(V, 1.0, 0.0); torch.cuda.synchronize()
+rows = []
+for which in (1, 2):
+    for i, op in enumerate(eng.cn.tapes[which]):
+        if op.kind not in (nv.OP_IGEMM, nv.OP_WGRAD):
+            continue
+        R = op.n_img * op.OH * op.OW
+        if op.kind == nv.OP_IGEMM:
+            fl = 0; desc = []
+            for q in range(op.nseg):
+                sg = op.seg[q]
+                fl += 2 * R * op.N * sg.KH * sg.KW * sg.C if sg.mode == 0 else 2 * op.n_img * sg.IH * sg.IW * sg.C * sg.KH * sg.KW * op.N
+                desc.append(f"m{sg.mode} {sg.KH}x{sg.KW}x{sg.C} s{sg.stride}")
+            name = f"igemm R={R} N={op.N} [" + "; ".join(desc) + "]"
+        else:
+            fl = 2 * R * op.N * op.M
+            name = f"wgrad R={R} N={op.N} M={op.M}"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        for r in range(reps + 1):
+            if r == 1:
+                e0.record()
+            nv.check(eng.lib.lip_debug_run_ops(eng.h, which, i, 1, nv.ptr(V), nv.ptr(Y), nv.ptr(H), P, nv.HEAD_GGN, 1.0,
+                                               nv.stream_ptr()), "debug_run_ops")
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        rows.append((which, i, name, ms, fl * P / ms / 1e9))
+tot = sum(r[3] for r in rows)
+for which, i, name, ms, tf in rows:
+    print(f"t{which} op{i:3d} {ms:7.3f} ms {tf:6.1f} TF  {name}")
+print("total ms", tot)
