@@ -69,6 +69,7 @@ struct WgradP {
   const float* scale;                   // per-channel [N] or null
   int ksplit;
   const float* zeros;
+  int P;                                // probe-batched variant: probes in this launch (columns = P*N)
 };
 
 struct ReduceP {

@@ -37,7 +37,8 @@ struct Tile {
   static constexpr int BN = WN * TN * 32;
   static constexpr int AE = BM * BK / NT;   // A floats per thread per K-tile
   static constexpr int AQ = AE / 4;         // A float4 per thread per K-tile
-  static constexpr int BE = BN * BK / NT;   // B floats per thread per K-tile
+  static constexpr int BE = (BN * BK + NT - 1) / NT;   // B floats per thread per K-tile (last one partial when WM = 3)
+  static constexpr bool BPART = (BN * BK) % NT != 0;
 };
 
 // One BK-deep MFMA sweep over the LDS tiles.
@@ -812,21 +813,27 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
 // Thread-invariant: its kernel tap (kh, kw, ci) and LDS / B offsets.  Per 16-row K-step each float4
 // gather costs two magic-number divisions + a branch-free bounds test.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool PB = false>
 __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP prm) {
   using T = Tile<WM, WN, TM, TN>;
-  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;
+  constexpr int BQ = (BN * BK / 4 + NT - 1) / NT;          // PB: B float4 per thread per K-tile
+  constexpr bool BQPART = (BN * BK / 4) % NT != 0;
+  constexpr int BE = PB ? 4 * BQ : T::BE;
   constexpr int LDA = BM + 4, LDB = BN;
   constexpr int QPR = BM / 4;
   __shared__ __attribute__((aligned(16))) float As[2 * BK * LDA];
-  __shared__ float Bs[2 * BK * LDB];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BK * LDB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  // PB (probe-batched): the probes are laid side by side along the GEMM's N axis — column j = (probe j / N, channel
+  // j % N) — so one 128-column tile serves 128 / N probes and the gathered activation tile is shared by all of them
   const int N = prm.N, M = prm.M;
-  const int tiles_n = (N + BN - 1) / BN;
+  const int NC = PB ? prm.P * N : N;           // GEMM columns of this launch
+  const int tiles_n = (NC + BN - 1) / BN;
   const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
-  const int p = blockIdx.y;
+  const int p = PB ? 0 : blockIdx.y;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int rows_per = (prm.R + prm.ksplit - 1) / prm.ksplit;
@@ -855,16 +862,25 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     tww = kw - prm.pad_w;
   }
   const int krow0 = tid / QPR;                    // row of quad j inside the K-step: krow0 + j*(NT/QPR)
-  unsigned bidx[BE];
-  int bk[BE];
-  bool bok[BE];
+  constexpr int NB = PB ? BQ : BE;                // B load instructions per thread per K-tile
+  unsigned bidx[NB];
+  int bk[NB];
+  bool bok[NB];
 #pragma unroll
-  for (int j = 0; j < BE; ++j) {
+  for (int j = 0; j < NB; ++j) {
     const int e = tid + j * NT;
-    const int k = e / BN, nn = e - k * BN;
-    bk[j] = k;
-    bok[j] = (n0 + nn) < N;
-    bidx[j] = (unsigned)(k * N + n0 + nn);
+    if (PB) {                                     // float4 along the channels of one probe (N % 4 == 0)
+      const int k = e / (BN / 4), nq = e - k * (BN / 4);
+      bk[j] = k;
+      bok[j] = (n0 + 4 * nq) < NC && (!BQPART || e < BN * BK / 4);
+      const int jc = bok[j] ? n0 + 4 * nq : 0, pj = jc / N;
+      bidx[j] = (unsigned)((long long)pj * prm.g_ps + k * N + (jc - pj * N));     // < 2^32 floats (host-checked)
+    } else {
+      const int k = e / BN, nn = e - k * BN;
+      bk[j] = k;
+      bok[j] = (n0 + nn) < NC && (!T::BPART || e < BN * BK);
+      bidx[j] = (unsigned)(k * N + n0 + nn);
+    }
   }
 
   const float* gp = prm.g + (long long)p * prm.g_ps + (long long)rbeg * N;
@@ -884,9 +900,14 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
       areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
     }
 #pragma unroll
-    for (int j = 0; j < BE; ++j) {
+    for (int j = 0; j < NB; ++j) {
       const float* src = (bok[j] && (rk0 + bk[j]) < rend) ? (gp + bidx[j]) : prm.zeros;
-      breg[j] = *src;
+      if (PB) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        breg[4 * j + 0] = v.x; breg[4 * j + 1] = v.y; breg[4 * j + 2] = v.z; breg[4 * j + 3] = v.w;
+      } else {
+        breg[j] = *src;
+      }
     }
   };
   auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
@@ -898,10 +919,17 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
           make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
     }
 #pragma unroll
-    for (int j = 0; j < BE; ++j) {
+    for (int j = 0; j < NB; ++j) {
       const int e = tid + j * NT;
-      const int k = e / BN, nn = e - k * BN;
-      Bsb[k * LDB + nn] = breg[j];
+      if (PB) {
+        const int k = e / (BN / 4), nq = e - k * (BN / 4);
+        if (!BQPART || e < BN * BK / 4)
+          *reinterpret_cast<float4*>(&Bsb[k * LDB + 4 * nq]) =
+              make_float4(breg[4 * j + 0], breg[4 * j + 1], breg[4 * j + 2], breg[4 * j + 3]);
+      } else {
+        const int k = e / BN, nn = e - k * BN;
+        if (!T::BPART || e < BN * BK) Bsb[k * LDB + nn] = breg[j];
+      }
     }
   };
 
@@ -918,8 +946,13 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
   float* ybase = prm.y + (long long)p * prm.y_ps;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + (wn * TN + tn) * 32 + l31;
-    if (col >= N) continue;
+    int col = n0 + (wn * TN + tn) * 32 + l31;
+    if (col >= NC) continue;
+    if (PB) {
+      const int pj = col / N;
+      col -= pj * N;
+      ybase = prm.y + (long long)pj * prm.y_ps;
+    }
     const float sc = prm.scale ? prm.scale[col] : 1.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -997,6 +1030,7 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
     static const bool dbg = getenv("LIP_DBG") != nullptr;       // diagnostic stamps (never in a timed run)
     static unsigned long long* dbgbuf = nullptr;
     q.dbg = nullptr;
+
     if (dbg) {
       if (!dbgbuf && hipMalloc((void**)&dbgbuf, 3 * 8192 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
       (void)hipMemsetAsync(dbgbuf, 0, 3 * 8192 * sizeof(unsigned long long), st);
@@ -1075,11 +1109,39 @@ static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Probe-batched weight gradient (N <= 64): columns = P*N, 128-column tiles; 96-row tiles (three waves) when
+// M = KH*KW*C is a multiple of 96 but not of 128 (288, 576).  The row reduction is split (float atomics) until
+// the launch has ~6 blocks per CU.
+template <int WM, int WN, int TM, int TN>
+static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
+  using T = Tile<WM, WN, TM, TN>;
+  const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * (((long long)P * p.N + T::BN - 1) / T::BN);
+  WgradP q = p;
+  q.zeros = zero_page();
+  if (!q.zeros) return hipErrorOutOfMemory;
+  q.P = P;
+  if (p.ksplit <= 1) {
+    long long ks = (1536 + tiles - 1) / tiles;
+    const long long maxks = (p.R + 64 * BK - 1) / (64 * BK);        // >= 64 K-tiles per split
+    if (ks > maxks) ks = maxks;
+    q.ksplit = ks < 1 ? 1 : (int)ks;
+  }
+  dim3 grid((unsigned)tiles, 1, (unsigned)q.ksplit);
+  hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
+  return hipGetLastError();
+}
+
 hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
-  // 64-row tiles when they waste fewer padded rows of M = KH*KW*Cin than 128-row tiles (M = 288: 320 vs 384)
-  static const int wg64 = getenv("LIP_WG64") ? atoi(getenv("LIP_WG64")) : 0;   // measured r15: 54.6 vs 52.4 ms -> off
-  const int waste128 = (p.M + 127) / 128 * 128 - p.M, waste64 = (p.M + 63) / 64 * 64 - p.M;
-  const bool small_m = p.M <= 64 || (wg64 && waste64 < waste128);
+  static const bool nopb = getenv("LIP_NOPB") != nullptr || getenv("LIP_GENERIC") != nullptr;   // A/B switch
+  const bool pb_ok = !nopb && P > 1 && p.N <= 64 && (p.N & 3) == 0 && p.M >= 96 && (p.g_ps & 3) == 0 && (((uintptr_t)p.g) & 15) == 0 && (p.C & 3) == 0 && (((uintptr_t)p.a) & 15) == 0 &&
+                     (long long)(P - 1) * p.g_ps + (long long)p.R * p.N < (1ll << 32);
+  // measured on MI355X (CIFAR ResNet1M, P = 256): N = 32, M = 288: 3.72 -> 2.67 ms; N = 64, M = 288: 1.58 -> 1.36 ms;
+  // N = 64, M = 576 (11% padded rows with 128-row tiles): 2.61 -> 2.68 ms, so that case stays per-probe
+  const int waste128 = (p.M + 127) / 128 * 128 - p.M;
+  if (pb_ok && (p.N <= 32 || 5 * waste128 >= p.M))
+    return (p.M % 96 == 0 && p.M % 128 != 0) ? run_wgrad_pb<3, 1, 1, 4>(p, P, st) : run_wgrad_pb<2, 2, 2, 2>(p, P, st);
+  // (64-row per-probe tiles for M = 288 were measured slower than 128-row ones: 54.6 vs 52.4 ms per step — removed)
+  const bool small_m = p.M <= 64;
   if (p.N > 64) return small_m ? run_wgrad<2, 2, 1, 2>(p, P, st) : run_wgrad<2, 2, 2, 2>(p, P, st);
   if (p.N > 32) return small_m ? run_wgrad<2, 2, 1, 1>(p, P, st) : run_wgrad<4, 1, 1, 2>(p, P, st);
   return small_m ? run_wgrad<2, 1, 1, 1>(p, P, st) : run_wgrad<4, 1, 1, 1>(p, P, st);
