@@ -9,13 +9,13 @@ OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 5 --warmup 2 --samples 0 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o run -- python3 $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats pass done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o run -- python3 $ARGS > /dev/null 2> "$OUT/fetch.err"
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o run -- python3 $ARGS > /dev/null 2> "$OUT/fetch.err"
 echo "fetch pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/write" -o run -- python3 $ARGS > /dev/null 2> "$OUT/write.err"
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/write" -o run -- python3 $ARGS > /dev/null 2> "$OUT/write.err"
 echo "write pass done"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/sq" -o run -- python3 $ARGS > /dev/null 2> "$OUT/sq.err"
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/sq" -o run -- python3 $ARGS > /dev/null 2> "$OUT/sq.err"
 echo "sq pass done"
 # keep only what the summariser reads (the merge back is capped at 64 MiB)
 find "$OUT" -name "*.csv" ! -name "*_kernel_stats.csv" ! -name "*_counter_collection.csv" -delete

@@ -18,7 +18,7 @@ src, tag = sys.argv[1], sys.argv[2]
 
 
 def counters(sub):
-    f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
+    f = sorted(glob.glob(f"{src}/{sub}/**/*_counter_collection.csv", recursive=True))[0]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0.0, 0]))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -28,7 +28,7 @@ def counters(sub):
     return acc
 
 
-shutil.copy(glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(sorted(glob.glob(f"{src}/stats/**/*_kernel_stats.csv", recursive=True))[0], f"profiles/{tag}_kernel_stats.csv")
 fetch, write, sq = counters("fetch"), counters("write"), counters("sq")
 traffic = {}
 for k in fetch:
