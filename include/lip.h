@@ -148,6 +148,10 @@ int lip_ggn_vp(lip_engine_t* e, const float* V, float* Y, int32_t P, float scale
 int lip_jvp(lip_engine_t* e, const float* V, float* U, int32_t P, int32_t head_mode, float c, void* stream);
 /* Y[p] = sum_i J_i^T (c * L_i U[p,i,:])  (LIP_HEAD_L, src/ggn.py:64-76,87-91) or raw (LIP_HEAD_IN) */
 int lip_vjp(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_mode, float c, void* stream);
+/* per-example rows of the same product: Y[(p*n + i)] = J_i^T (c * L_i U[p,i,:]), Y is (P*n, D) — no reduction
+ * crosses examples, so a probe that holds e_k on every example yields the n rows J_i^T L_i e_k of the GGN's
+ * square-root factor in ONE sweep (the reference builds them column by column: src/ggn.py:64-93, 207-219) */
+int lip_vjp_rows(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_mode, float c, void* stream);
 
 /* ---- Krylov / trace primitives on blocks of vectors: X is (P, N) row-major -----------
  * They replace what XLA emits for matfree's tridiag_sym (called at src/sample.py:114-126),

@@ -68,6 +68,7 @@ SIGNATURES = {
     "lip_ggn_vp": (C.c_int, [_V, _V, _V, C.c_int32, C.c_float, C.c_float, _V]),
     "lip_jvp": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_float, _V]),
     "lip_vjp": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_float, _V]),
+    "lip_vjp_rows": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_float, _V]),
     "lip_bdot": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int64, _V]),
     "lip_axpby": (C.c_int, [_V, _V, _V, C.c_float, _V, C.c_float, C.c_int32, C.c_int64, _V]),
     "lip_multi_dot": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _V]),

@@ -55,6 +55,7 @@ struct RunCtx {
   int head_mode;
   float head_c;
   hipStream_t st;
+  bool rows = false;   // lip_vjp_rows: Y holds one row per (probe, example); no reduction crosses examples
 };
 
 inline float* resolve(const RunCtx& c, const lip_ref_t& r) {
@@ -70,11 +71,30 @@ inline float* resolve(const RunCtx& c, const lip_ref_t& r) {
   }
 }
 
+// lip_vjp_rows: the parameter reductions an op would fuse (bias / BN cotangents: column sums over ALL rows of a
+// probe) are taken per example instead, by a segmented reduce over the op's freshly written output.
+struct RowReds { float* red0; float* red1; const float* xhat; };
+
 #define RUN_CHECK(expr, what)                                                                  \
   do {                                                                                         \
     hipError_t _e = (expr);                                                                    \
     if (_e != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(_e)); return LIP_ERR_HIP; } \
   } while (0)
+
+// Segmented (per-example) parameter reductions of lip_vjp_rows, taken over an op's output tensor [P][n][rows][N].
+int rows_reduce(const RunCtx& c, const float* out, long long out_ps, int n_img, int rows, int N, const float* xhat,
+                float* red0, long long red0_ps, float* red1, long long red1_ps) {
+  if (!red0 && !red1) return LIP_OK;
+  ReduceP r;
+  memset(&r, 0, sizeof(r));
+  r.g = out; r.g_ps = out_ps; r.R = rows; r.N = N; r.xhat = xhat;
+  r.red0 = red0; r.red1 = red1;
+  r.nseg = n_img; r.red_seg = red0 ? red0_ps : red1_ps;
+  r.red0_ps = red0_ps * n_img; r.red1_ps = red1_ps * n_img;
+  if (N <= 0 || N > 8192 || (red1 && !xhat)) { set_error("per-example reduce: bad operands"); return LIP_ERR_ARG; }
+  RUN_CHECK(launch_reduce(r, c.P, c.st), "per-example reduce launch");
+  return LIP_OK;
+}
 
 int check_space(const RunCtx& c, const lip_ref_t& r, const char* what) {
   if (r.space == LIP_SP_NONE) return LIP_OK;
@@ -120,6 +140,12 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       if (!p.out || p.R <= 0 || p.N <= 0) { set_error("IGEMM: bad output"); return LIP_ERR_ARG; }
       if (p.e1 && !p.xhat) { set_error("IGEMM: e1 without xhat"); return LIP_ERR_ARG; }
       if (p.red1 && !p.xhat2) { set_error("IGEMM: red1 without xhat2"); return LIP_ERR_ARG; }
+      if (c.rows && (p.red0 || p.red1)) {
+        float* r0 = p.red0; float* r1 = p.red1;
+        p.red0 = nullptr; p.red1 = nullptr;
+        RUN_CHECK(launch_igemm(p, c.P, c.st), "igemm launch");
+        return rows_reduce(c, p.out, p.out_ps, op.n_img, p.OHW, p.N, p.xhat2, r0, p.red0_ps, r1, p.red1_ps);
+      }
       RUN_CHECK(launch_igemm(p, c.P, c.st), "igemm launch");
       return LIP_OK;
     }
@@ -137,7 +163,9 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       p.y = resolve(c, op.out); p.y_ps = op.out.pstride;
       p.scale = resolve(c, op.scale);
       p.ksplit = op.ksplit > 0 ? op.ksplit : 1;
-      if (op.ksplit <= 0) {
+      if (c.rows) {
+        p.ksplit = op.n_img; p.seg_rows = p.OHW; p.seg_ys = p.y_ps; p.y_ps *= op.n_img;
+      } else if (op.ksplit <= 0) {
         // few probes: split the row reduction (float atomics) so the launch still fills 256 CUs
         const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * c.P;
         if (tiles < 512) {
@@ -162,6 +190,10 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       p.red0 = resolve(c, op.red0); p.red0_ps = op.red0.pstride;
       p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
       if (!p.g || p.N <= 0 || p.N > 8192 || (p.red1 && !p.xhat)) { set_error("REDUCE: bad operands"); return LIP_ERR_ARG; }
+      if (c.rows) {
+        p.R = op.OH * op.OW; p.nseg = op.n_img; p.red_seg = p.red0 ? p.red0_ps : p.red1_ps;
+        p.red0_ps *= op.n_img; p.red1_ps *= op.n_img;
+      }
       RUN_CHECK(launch_reduce(p, c.P, c.st), "reduce launch");
       return LIP_OK;
     }
@@ -178,6 +210,12 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
       if (!p.in || !p.out || p.C <= 0 || p.C > 8192 || (p.red1 && !p.xhat)) { set_error("POOL: bad operands"); return LIP_ERR_ARG; }
       if (op.kind == LIP_OP_POOL_FWD) RUN_CHECK(launch_pool_fwd(p, c.P, c.st), "pool_fwd launch");
+      else if (c.rows && (p.red0 || p.red1)) {
+        float* r0 = p.red0; float* r1 = p.red1;
+        p.red0 = nullptr; p.red1 = nullptr;
+        RUN_CHECK(launch_pool_bwd(p, c.P, c.st), "pool_bwd launch");
+        return rows_reduce(c, p.out, p.out_ps, p.n, p.HW, p.C, p.xhat, r0, p.red0_ps, r1, p.red1_ps);
+      }
       else RUN_CHECK(launch_pool_bwd(p, c.P, c.st), "pool_bwd launch");
       return LIP_OK;
     }
@@ -199,6 +237,12 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       if (!p.in || !p.out || p.C <= 0 || p.C > 8192 || p.stride <= 0 || (p.red1 && !p.xhat)) { set_error("MAXPOOL: bad operands"); return LIP_ERR_ARG; }
       if (op.kind == LIP_OP_MAXPOOL_PRIMAL) RUN_CHECK(launch_maxpool_primal(p, c.st), "maxpool_primal launch");
       else if (op.kind == LIP_OP_MAXPOOL_FWD) RUN_CHECK(launch_maxpool_fwd(p, c.P, c.st), "maxpool_fwd launch");
+      else if (c.rows && (p.red0 || p.red1)) {
+        float* r0 = p.red0; float* r1 = p.red1;
+        p.red0 = nullptr; p.red1 = nullptr;
+        RUN_CHECK(launch_maxpool_bwd(p, c.P, c.st), "maxpool_bwd launch");
+        return rows_reduce(c, p.out, p.out_ps, p.n, p.IH * p.IW, p.C, p.xhat, r0, p.red0_ps, r1, p.red1_ps);
+      }
       else RUN_CHECK(launch_maxpool_bwd(p, c.P, c.st), "maxpool_bwd launch");
       return LIP_OK;
     }
@@ -290,7 +334,7 @@ int ready(const lip_engine* e, const char* who) {
 
 extern "C" {
 
-int lip_abi_version(void) { return 2; }
+int lip_abi_version(void) { return 3; }
 const char* lip_last_error(void) { return g_err; }
 int lip_sizeof_op(void) { return (int)sizeof(lip_op_t); }
 int lip_set_precision(int32_t mode) { if (mode != 0 && mode != 1) { set_error("lip_set_precision: mode must be 0 (f32) or 1 (bf16x3)"); return LIP_ERR_ARG; } set_precision_mode(mode); return LIP_OK; }
@@ -421,6 +465,22 @@ int lip_vjp(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_m
     float* y = Y + (int64_t)c0 * e->D;
     RUN_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)pc * e->D, st), "memset Y");
     RunCtx c{e, nullptr, y, const_cast<float*>(U) + (int64_t)c0 * hstride, pc, head_mode, cc, st};
+    if ((rc = run_tape(c, LIP_TAPE_BACKWARD, false))) return rc;
+  }
+  return LIP_OK;
+}
+
+int lip_vjp_rows(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_mode, float cc, void* stream) {
+  int rc = ready(e, "lip_vjp_rows");
+  if (rc) return rc;
+  if (!U || !Y || P <= 0 || (head_mode != LIP_HEAD_L && head_mode != LIP_HEAD_IN)) { set_error("lip_vjp_rows: bad argument"); return LIP_ERR_ARG; }
+  const int64_t hstride = (int64_t)e->n_img * e->K, ystride = (int64_t)e->n_img * e->D;
+  hipStream_t st = (hipStream_t)stream;
+  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
+    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+    float* y = Y + (int64_t)c0 * ystride;
+    RUN_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)pc * ystride, st), "memset Y");
+    RunCtx c{e, nullptr, y, const_cast<float*>(U) + (int64_t)c0 * hstride, pc, head_mode, cc, st, true};
     if ((rc = run_tape(c, LIP_TAPE_BACKWARD, false))) return rc;
   }
   return LIP_OK;

@@ -70,6 +70,9 @@ struct WgradP {
   int ksplit;
   const float* zeros;
   int P;                                // probe-batched variant: probes in this launch (columns = P*N)
+  // per-example rows (lip_vjp_rows): grid.z = example, the row reduction of block z covers only that example's
+  // seg_rows = OH*OW rows and lands in Y row (p, z): y + p*y_ps + z*seg_ys
+  int seg_rows; long long seg_ys;
 };
 
 struct ReduceP {
@@ -77,6 +80,8 @@ struct ReduceP {
   const float* xhat;
   float* red0; long long red0_ps;
   float* red1; long long red1_ps;
+  // per-example rows: nseg > 0 -> grid.z = example, R rows per example, outputs at + z*red_seg
+  int nseg; long long red_seg;
 };
 
 struct PoolP {

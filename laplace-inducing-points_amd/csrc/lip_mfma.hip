@@ -669,6 +669,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
 
   int rows_per = (prm.R + prm.ksplit - 1) / prm.ksplit;
   rows_per = (rows_per + BK - 1) / BK * BK;
+  if (prm.seg_rows) rows_per = prm.seg_rows;           // per-example rows: block z reduces example z only
   const int rbeg = blockIdx.z * rows_per;
   const int rend = min(prm.R, rbeg + rows_per);
   if (rbeg >= rend) return;
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
   }
 
   const int l31 = lane & 31, lh = lane >> 5;
-  float* ybase = prm.y + (long long)p * prm.y_ps;
+  float* ybase = prm.y + (long long)p * prm.y_ps + (prm.seg_rows ? (long long)blockIdx.z * prm.seg_ys : 0);
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = n0 + (wn * TN + tn) * 32 + l31;
@@ -838,6 +839,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
 
   int rows_per = (prm.R + prm.ksplit - 1) / prm.ksplit;
   rows_per = (rows_per + BK - 1) / BK * BK;
+  if (prm.seg_rows) rows_per = prm.seg_rows;           // per-example rows: block z reduces example z only
   const int rbeg = blockIdx.z * rows_per;
   const int rend = min(prm.R, rbeg + rows_per);
   if (rbeg >= rend) return;
@@ -943,7 +945,8 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
       [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
 
   const int l31 = lane & 31, lh = lane >> 5;
-  float* ybase = prm.y + (long long)p * prm.y_ps;
+  const long long yseg = prm.seg_rows ? (long long)blockIdx.z * prm.seg_ys : 0;
+  float* ybase = prm.y + (long long)p * prm.y_ps + yseg;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     int col = n0 + (wn * TN + tn) * 32 + l31;
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     if (PB) {
       const int pj = col / N;
       col -= pj * N;
-      ybase = prm.y + (long long)pj * prm.y_ps;
+      ybase = prm.y + (long long)pj * prm.y_ps + yseg;
     }
     const float sc = prm.scale ? prm.scale[col] : 1.f;
 #pragma unroll
@@ -1120,7 +1123,7 @@ static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
   q.zeros = zero_page();
   if (!q.zeros) return hipErrorOutOfMemory;
   q.P = P;
-  if (p.ksplit <= 1) {
+  if (p.ksplit <= 1 && !p.seg_rows) {
     long long ks = (1536 + tiles - 1) / tiles;
     const long long maxks = (p.R + 64 * BK - 1) / (64 * BK);        // >= 64 K-tiles per split
     if (ks > maxks) ks = maxks;

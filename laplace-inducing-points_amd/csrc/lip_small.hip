@@ -15,8 +15,9 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceP prm) {
   __syncthreads();
   const int rbeg = blockIdx.x * RED_ROWS;
   const int rows = min(RED_ROWS, prm.R - rbeg);
-  const float* g = prm.g + (long long)p * prm.g_ps + (long long)rbeg * N;
-  const float* xh = prm.xhat ? prm.xhat + (long long)rbeg * N : nullptr;
+  const long long seg0 = (long long)blockIdx.z * prm.R * N;      // per-example rows: segment z of R rows
+  const float* g = prm.g + (long long)p * prm.g_ps + seg0 + (long long)rbeg * N;
+  const float* xh = prm.xhat ? prm.xhat + seg0 + (long long)rbeg * N : nullptr;
   const long long cnt = (long long)rows * N;
   if (N <= 256 && (256 % N) == 0) {
     // fixed channel per thread: accumulate privately, one LDS atomic per thread
@@ -39,13 +40,13 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceP prm) {
   }
   __syncthreads();
   for (int c = threadIdx.x; c < N; c += 256) {
-    if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + c, s0[c]);
-    if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + c, s1[c]);
+    if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + blockIdx.z * prm.red_seg + c, s0[c]);
+    if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + blockIdx.z * prm.red_seg + c, s1[c]);
   }
 }
 
 hipError_t launch_reduce(const ReduceP& p, int P, hipStream_t st) {
-  dim3 grid((p.R + RED_ROWS - 1) / RED_ROWS, P, 1);
+  dim3 grid((p.R + RED_ROWS - 1) / RED_ROWS, P, p.nseg > 0 ? p.nseg : 1);
   hipLaunchKernelGGL(reduce_kernel, grid, dim3(256), 2 * p.N * sizeof(float), st, p);
   return hipGetLastError();
 }

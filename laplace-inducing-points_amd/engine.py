@@ -618,3 +618,13 @@ class LinearizedNet:
         m = nv.HEAD_L if mode == "l" else nv.HEAD_IN
         nv.check(self.lib.lip_vjp(self.h, nv.ptr(Ub), nv.ptr(Y), Ub.shape[0], m, float(c), nv.stream_ptr()), "lip_vjp")
         return Y
+
+    def vjp_rows(self, U: torch.Tensor, mode: str = "raw", c: float = 1.0) -> torch.Tensor:
+        """Per-example rows of :meth:`vjp`: ``out[p, i] = J_i^T (c L_i U[p, i])`` -> (P, n, D).  Nothing is summed
+        over examples, so the cost is that of ONE backward sweep per probe for all n rows."""
+        Ub = U.reshape(-1, self.n * self.K).to(device=self.device, dtype=torch.float32).contiguous()
+        Y = torch.empty(Ub.shape[0], self.n, self.D, device=self.device, dtype=torch.float32)
+        m = nv.HEAD_L if mode == "l" else nv.HEAD_IN
+        nv.check(self.lib.lip_vjp_rows(self.h, nv.ptr(Ub), nv.ptr(Y), Ub.shape[0], m, float(c), nv.stream_ptr()),
+                 "lip_vjp_rows")
+        return Y

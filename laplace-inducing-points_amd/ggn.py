@@ -107,10 +107,18 @@ class ExampleChunkedGGN:
     rows = __call__
 
 
-def materialize_factor(eng: LinearizedNet, c: float = 1.0, block: Optional[int] = None) -> torch.Tensor:
+def materialize_factor(eng: LinearizedNet, c: float = 1.0, block: Optional[int] = None,
+                       per_example: bool = True) -> torch.Tensor:
     """Wm (d, D) with rows c * J_i^T L_i e_k — the square-root factor W^T of the GGN (``src/ggn.py:9-93``)
-    written out: d = M K engine rows (one backward sweep with the one-hot block as cotangents)."""
+    written out, d = M K.  Row (i, k) depends on example i only: K probes that each hold e_k on EVERY example go
+    through one per-example backward sweep (``lip_vjp_rows``) and yield all M K rows — M times less arithmetic than
+    pushing the d one-hot cotangents through the summed ``vjp`` (kept as ``per_example=False``; measured at the
+    CIFAR config, d = 500: 184 ms -> see DESIGN §4)."""
     d = eng.n * eng.K
+    if per_example:
+        E = torch.eye(eng.K, device=eng.device, dtype=torch.float32)[:, None, :].expand(eng.K, eng.n, eng.K)
+        rows = eng.vjp_rows(E.contiguous(), "l", c)                       # (K, n, D)
+        return rows.permute(1, 0, 2).reshape(d, eng.D)
     bs = block or max(1, min(d, (2 << 30) // (4 * eng.D)))
     Wm = torch.empty(d, eng.D, device=eng.device, dtype=torch.float32)
     for s in range(0, d, bs):
@@ -125,14 +133,22 @@ FACTOR_BYTES_LIMIT = 64 << 30
 
 
 def gram_from_factor(Wm: torch.Tensor) -> torch.Tensor:
-    """Wm Wm^T (d, d) accumulated in float64, chunked over D: an fp32 Gram of a (d, 1e6) factor carries
-    ~1e-4 * max|G| of rounding noise, enough to push the (numerically zero) eigenvalues of W^T W negative."""
+    """Wm Wm^T (d, d) accumulated in float64: an fp32 Gram of a (d, 1e6) factor carries ~1e-4 * max|G| of rounding
+    noise, enough to push the (numerically zero) eigenvalues of W^T W negative.  The long axis is cut into slabs
+    that go through ONE batched float64 GEMM each (a single (d, d) product has only (d/128)^2 output tiles — 16 at
+    d = 500 — and leaves the chip idle: 176 ms measured; batched: the slab products fill it), then summed."""
     d, D = Wm.shape
     G = torch.zeros(d, d, device=Wm.device, dtype=torch.float64)
-    step = max(1, (256 << 20) // (8 * d))
-    for c in range(0, D, step):
-        blk = Wm[:, c:c + step].double()
-        G += blk @ blk.T
+    slab = 8192                                              # columns per batch entry
+    per_call = max(1, (1 << 30) // (8 * d * slab))           # batch entries per call: <= 1 GiB of float64 operands
+    body = (D // slab) * slab
+    for c in range(0, body, per_call * slab):
+        e = min(body, c + per_call * slab)
+        blk = Wm[:, c:e].reshape(d, (e - c) // slab, slab).permute(1, 0, 2).double()      # (B, d, slab)
+        G += torch.bmm(blk, blk.transpose(1, 2)).sum(0)
+    if body < D:
+        tail = Wm[:, body:].double()
+        G += tail @ tail.T
     return G
 
 

@@ -106,8 +106,16 @@ def test_engine_matches_tape_semantics(name):
     Jrr = tm.jvp(V, nv.HEAD_OUT, 1.0)
     Jt = eng.vjp(U, "raw")
     Jtr = tm.vjp(U, nv.HEAD_IN, 1.0)
+    # per-example rows (lip_vjp_rows): row (p, i) is the summed product of the cotangent masked to example i
+    rows = eng.vjp_rows(U, "l", 0.7)
     torch.cuda.synchronize()
-    errs = dict(ggn=_rel(Y, Yr), wt=_rel(Uh, Ur), w=_rel(Yw, Ywr), jvp=_rel(Jr, Jrr), vjp=_rel(Jt, Jtr))
+    assert rows.shape == (P, n, eng.D)
+    errs = dict(ggn=_rel(Y, Yr), wt=_rel(Uh, Ur), w=_rel(Yw, Ywr), jvp=_rel(Jr, Jrr), vjp=_rel(Jt, Jtr),
+                rows_sum=_rel(rows.sum(1), Ywr))
+    for i in sorted({0, n // 2, n - 1}):
+        Um = torch.zeros_like(U)
+        Um[:, i] = U[:, i]
+        errs[f"rows[{i}]"] = _rel(rows[:, i], tm.vjp(Um, nv.HEAD_L, 0.7))
     bad = {k: v for k, v in errs.items() if not (v <= tol)}
     if bad:
         msgs = _localise(eng, tm, V, None, P, nv.HEAD_GGN, scale, [1, 2])
@@ -127,6 +135,19 @@ def test_probe_chunking_and_single_vector():
     torch.cuda.synchronize()
     assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     assert torch.allclose(a[2], c[0], rtol=1e-4, atol=1e-5)   # split-K atomics reorder the sum
+
+
+def test_factor_rows_per_example_equal_one_hot_sweeps():
+    """materialize_factor: K probes through the per-example sweep == d one-hot cotangents through the summed vjp."""
+    from lip_amd.ggn import materialize_factor
+    for name in ("xor_classifier", "resnet_small", "sine_regressor"):
+        net, Z, model_type, _ = _cases()[name]
+        eng = LinearizedNet(create_state(net, 4, dtype=F64, logvar=-0.2), Z, model_type)
+        a = materialize_factor(eng, 0.9, per_example=True)
+        b = materialize_factor(eng, 0.9, per_example=False)
+        torch.cuda.synchronize()
+        assert a.shape == b.shape == (eng.n * eng.K, eng.D)
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item(), name
 
 
 def test_missing_netspec_fails_loudly():
