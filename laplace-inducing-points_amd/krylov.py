@@ -50,9 +50,10 @@ def fill_rademacher(P: int, N: int, seed: int, device="cuda") -> torch.Tensor:
     return X
 
 
-def fill_normal(P: int, N: int, seed: int, device="cuda") -> torch.Tensor:
+def fill_normal(P: int, N: int, seed: int, device="cuda", out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = nv.load()
-    X = torch.empty(P, N, device=device, dtype=torch.float32)
+    X = torch.empty(P, N, device=device, dtype=torch.float32) if out is None else _chk(out)
+    assert tuple(X.shape) == (P, N)
     nv.check(lib.lip_fill_normal(nv.ptr(X), P, N, int(seed) & (2 ** 64 - 1), nv.stream_ptr()), "lip_fill_normal")
     return X
 

@@ -123,6 +123,18 @@ class _SamplerParts:
         return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
 
 
+    def apply_(self, V: torch.Tensor) -> torch.Tensor:
+        """In-place :meth:`apply` for the materialised-factor case: the ``+ alpha^(-1/2) v`` term rides in the second
+        GEMM's epilogue (``beta * C``), so a block of draws costs two GEMM passes over Wm and nothing else."""
+        if self.Wm is None:
+            V.copy_(self.apply(V))
+            return V
+        U = V @ self.Wm.T
+        G = self.G_pinv
+        X = (self.f_small(U) @ G - (1.0 / math.sqrt(self.alpha)) * (U @ G)).contiguous()
+        return torch.addmm(V, X, self.Wm, beta=1.0 / math.sqrt(self.alpha), alpha=1.0, out=V)
+
+
 _PARTS_CACHE = {}
 
 
@@ -163,12 +175,12 @@ def sample(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=Non
     fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, key=None,
                          num_proj_steps=num_proj_steps, clip_min=clip_min, method=method)
     eng = fun.engine
-    outs = []
+    out = torch.empty(num_samples, eng.D, device=eng.device, dtype=torch.float32)
     for s in range(0, num_samples, block):
         e = min(num_samples, s + block)
-        Eps = krylov.fill_normal(e - s, eng.D, _seed(key) * 1000003 + s, eng.device)
-        outs.append(fun.rows(Eps))
-    return torch.cat(outs) if len(outs) > 1 else outs[0]
+        krylov.fill_normal(e - s, eng.D, _seed(key) * 1000003 + s, eng.device, out=out[s:e])
+        fun.parts.apply_(out[s:e])
+    return out
 
 
 def sample_lanczos(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None, num_matvecs=36,
