@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--n", type=int, default=50, help="examples (inducing points) per GPU")
     ap.add_argument("--samples", type=int, default=200, help="posterior samples for the samples/s line (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resnet50", action="store_true", help="skip the full-resolution ResNet-50 slice (configs[4])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,6 +240,31 @@ def main():
                                 "should call")
 
     # ---- Krylov / trace primitives: HBM roofline (algorithmic bytes / time, peak 8 TB/s spec) ------------------
+    # ---- BASELINE configs[4] slice: full-resolution ResNet-50 (25.6 M parameters, K = 1000), 8 images x 64 probes ---
+    r50_line = None
+    if args.samples > 0 and not args.no_resnet50 and rank == 0 and world == 1:
+        from lip_amd.scalemodels import ResNet50
+        from lip_amd.toymodels import create_state as _cs50
+        n50, P50 = 8, 64
+        st50 = _cs50(ResNet50(1000), seed=1, dtype=torch.float32)
+        e50 = LinearizedNet(st50, torch.rand(n50, 224, 224, 3, generator=torch.Generator().manual_seed(3)).to(dev),
+                            "classifier", workspace_bytes=64 << 30, max_chunk=P50)
+        V50 = krylov.fill_rademacher(P50, e50.D, 11, dev)
+        e50.ggn_vp(V50, 1.0, 0.0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            Y50 = e50.ggn_vp(V50, 1.0, 0.0)
+        torch.cuda.synchronize()
+        t50 = (time.perf_counter() - t1) / 3
+        f50 = sum(e50.flops_per_probe().values())
+        r50_line = dict(value=P50 / t50, unit="GGN-vp/s over 8 images", ms_per_block=1e3 * t50, D=e50.D,
+                        tflops=f50 * P50 / t50 / 1e12, frac_of_f32_mfma_peak=f50 * P50 / t50 / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        images=n50, probes=P50, finite=bool(torch.isfinite(Y50).all().item()),
+                        note="224x224x3 inputs, torchvision-style bottleneck ResNet-50, random init; a slice of configs[4] "
+                             "(1024 probes x 10k images over 8 GPUs = 160 such blocks x 16 probe chunks per GPU)")
+        del e50, V50, Y50
+
     krylov_line = None
     if args.samples > 0 and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -266,7 +292,7 @@ def main():
                                          "full_set_size=49000; data sum sharded over ranks, one all-reduce per matvec",
                                 examples_per_gpu=n, probes=P, D=eng.D, probe_chunk=eng.chunk,
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:
