@@ -2,9 +2,9 @@
 
 ``alternative_objective_dense`` (``:176-193``), ``alternative_objective_scalable_exact`` (``:26-84``) and
 ``alternative_objective_scalable`` (``:87-173``): KL[q(theta|Z) || q(theta|data)] up to constants =
-log-det term + trace term.  What is NOT here yet is the gradient w.r.t. Z (``value_and_grad`` at ``:195-196``,
-``optimize_step`` ``:199-232``): it needs second-order differentiation through the network and reverse mode
-through the Krylov solvers; ``variational_grad_*`` raise ``NotImplementedError``.
+log-det term + trace term, and their gradients w.r.t. Z (``value_and_grad`` at ``:195-196``, ``optimize_step``
+``:199-232``): exact, with every D-sized quantity on the HIP engine and only the last, second-order step (the input
+derivative of a parameter-JVP) on ``torch.func`` — see the comment block above ``variational_grad_scalable``.
 
 SURVEY §4.1-9: the reference's stochastic log-det omits beta (it bidiagonalises v -> [sqrt(alpha) v ; Wz^T v],
 ``:164-169``, i.e. log|alpha I + Wz Wz^T|) while its exact twin uses beta (``:68``).  ``logdet_beta=True`` (default)
@@ -115,13 +115,197 @@ def alternative_objective_scalable(Z, X, state, alpha, model_type, key, full_set
     return logdet_term + trace_term
 
 
-def _no_grad(*_a, **_k):
-    raise NotImplementedError(
-        "the gradient of the KL objective w.r.t. the inducing points Z (src/train_inducing.py:195-232) is not "
-        "implemented yet: it needs second-order differentiation through the network; only objective values are")
+# ----------------------------------------------------------------------------------------------------------------
+# gradients w.r.t. the inducing points (``src/train_inducing.py:195-232``)
+# ----------------------------------------------------------------------------------------------------------------
+# Both objectives have the form F(Z) = +-[tr(A P_z(Z)^{+-1}) ...] with P_z = alpha I + beta G(Z), G = sum_j W_j W_j^T,
+# W_j = c J(z_j)^T L(z_j) (D x K).  Differentiating with the D x D factor Q frozen,
+#     dF = beta tr(Q dG) = 2 beta sum_j <Q W_j, dW_j>          =>      grad_{z_j} F = 2 beta grad_z <M_j, W_j(z)>,
+# M = Q W (D x d).  Everything D-sized — the factors Wm (d, D) of Z and Wx of the data batch (per-example backward
+# sweeps of the HIP engine), their Gram matrices and M (GEMMs) — is exact linear algebra on the device; what is left
+# is the derivative of the scalar sum_{j,k} <J(z_j) m_jk, L(z_j) e_k> w.r.t. the inputs z_j: a reverse pass over a
+# parameter-JVP, i.e. second order in the network.  The hand-written tapes are first order; this last step runs on
+# torch.func (forward-over-reverse through ``NetSpec.forward`` on the GPU) — the one place of the package where a
+# derivative is not a HIP tape, stated in DESIGN §8 and to be replaced by a second-order tape.
+def _c_out(state, model_type):
+    return math.exp(-0.5 * float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0
 
 
-variational_grad_dense = _no_grad
-variational_grad_scalable = _no_grad
-optimize_step = _no_grad
-train_inducing_points = _no_grad
+def _gram64(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A B^T for (a, D) x (b, D) factors, float64 accumulation in slabs of the long axis."""
+    a, D = A.shape
+    out = torch.zeros(a, B.shape[0], device=A.device, dtype=torch.float64)
+    step = max(1, (512 << 20) // (8 * max(a, B.shape[0])))
+    for c in range(0, D, step):
+        out += A[:, c:c + step].double() @ B[:, c:c + step].double().T
+    return out
+
+
+def _factor_of(state, X, model_type):
+    from .ggn import get_engine, materialize_factor
+    eng = get_engine(state, X, model_type)
+    return eng, materialize_factor(eng, _c_out(state, model_type))
+
+
+def _input_grad_of_pairing(state, Z, Mrow, model_type):
+    """grad_Z of  sum_{j,k} < Mrow[(j,k)], W_(j,k)(z_j) >  =  sum_{j,k} < J(z_j) m_jk, c L(z_j) e_k >   (torch.func)."""
+    from torch.func import grad, jvp, vmap
+    net = state.net
+    dev = Mrow.device
+    flat, unravel = flatten_nn_params(state.params)
+    flat = flat.to(device=dev, dtype=torch.float32)
+    stats = state.to(device=dev, dtype=torch.float32).batch_stats
+    root = net.param_root
+    n = Z.shape[0]
+    Kout = net.num_outputs
+    c = _c_out(state, model_type)
+
+    def wrap(theta):
+        tree = unravel(theta)
+        return tree
+
+    def f(theta, z):
+        return net.forward(wrap(theta), stats, z).reshape(-1)               # (K,)
+
+    def phi_one(z, Mj):                                                      # Mj (K rows, D)
+        JM = vmap(lambda m: jvp(lambda th: f(th, z), (flat,), (m,))[1])(Mj)   # (K rows, K): row k = J(z) m_k
+        if model_type == "classifier":
+            p = torch.softmax(f(flat, z), dim=-1)
+            sq = torch.sqrt(p)
+            L = torch.diag(sq) - torch.outer(p, sq)                          # src/ggn.py:27-33, column k = L e_k
+            return (JM * L.T).sum()
+        return c * torch.diagonal(JM).sum()
+
+    Zd = Z.to(device=dev, dtype=torch.float32)
+    Mj = Mrow.reshape(n, Kout, -1)
+    try:
+        return grad(lambda Zb: vmap(phi_one)(Zb, Mj).sum())(Zd)
+    except (RuntimeError, NotImplementedError):
+        # a layer without a batching rule under the nested vmap: one example at a time
+        return torch.stack([grad(lambda z: phi_one(z, Mj[j]))(Zd[j]) for j in range(n)])
+
+
+def variational_grad_scalable(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None,
+                              x_chunk: Optional[int] = None, **_):
+    """``jax.value_and_grad(alternative_objective_scalable)`` (``src/train_inducing.py:196``) -> ``(loss, dLoss/dZ)``.
+
+    The objective is F(Z) = tr(P S_z) + log det P_z  (P = alpha I + gamma G_X the data precision, S_z = P_z^-1), the
+    quantity the reference's Hutch++ / SLQ estimators target (``:87-173``; exact twin ``:26-84``).  Returned are its
+    EXACT value (through the small Gram matrices, constants dropped as in ``:68,82``) and EXACT gradient, not the
+    gradient of a stochastic estimate: in the inducing regime the factors fit in HBM and exactness is cheaper than
+    the estimators' variance.  The data batch is consumed in chunks of ``x_chunk`` examples."""
+    from .ggn import gram_from_factor
+    N = full_set_size or Z.shape[0]
+    M_, Kb = Z.shape[0], X.shape[0]
+    beta, gamma = N / M_, N / Kb
+    engz, Wm = _factor_of(state, Z, model_type)
+    dev, D = Wm.device, engz.D
+    d = Wm.shape[0]
+    Gd = gram_from_factor(Wm)
+    Gd = 0.5 * (Gd + Gd.T)
+    lam, U = torch.linalg.eigh(Gd)
+    lam = lam.clamp_min(0.0)
+    cdiag = 1.0 / (alpha + beta * lam)                                      # C = (alpha I + beta Gd)^-1
+    C = (U * cdiag) @ U.T
+    Mrow = torch.zeros_like(Wm)
+    H = torch.zeros(d, d, device=dev, dtype=torch.float64)                  # Gxz^T Gxz
+    tr_x = 0.0
+    step = x_chunk or Kb
+    for s0 in range(0, Kb, step):
+        Xc = X[s0:s0 + step]
+        _, Wx = _factor_of(state, Xc, model_type)
+        Gxz = _gram64(Wx, Wm)                                               # (dx_c, d)
+        H += Gxz.T @ Gxz
+        A2 = (gamma / alpha) * (Gxz @ C)                                    # (dx_c, d)
+        Mrow.addmm_(A2.T.float(), Wx, beta=1.0, alpha=-1.0)
+        del Wx
+    A1 = (U * (beta * lam * cdiag * cdiag)) @ U.T + (gamma * beta / alpha) * (C @ H @ C)
+    Mrow.addmm_(A1.float(), Wm, beta=1.0, alpha=1.0)
+    gZ = 2.0 * beta * _input_grad_of_pairing(state, Z, Mrow, model_type)
+    # exact value, the reference's scalable_exact formula (:60-84)
+    a_inv = 1.0 / alpha
+    logdet_term = torch.log1p(beta * a_inv * lam).sum() + D * math.log(alpha)
+    Minv = (U * (1.0 / (1.0 / beta + a_inv * lam))) @ U.T                   # (beta^-1 I + alpha^-1 Gd)^-1
+    trace1 = (Minv * Gd).sum()
+    trace2 = (Minv * H).sum()
+    loss = float(logdet_term - a_inv * trace1 - gamma * a_inv ** 2 * trace2)
+    return loss, gZ.reshape(Z.shape).to(Z.dtype)
+
+
+def variational_grad_dense(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None, **_):
+    """``jax.value_and_grad(alternative_objective_dense)`` (``src/train_inducing.py:195``): F(Z) = tr(S P_z) - log det
+    P_z with S = (alpha I + gamma G_X)^-1.  Frozen factor Q = S - S_z; S W through Woodbury on the data factor."""
+    from .ggn import gram_from_factor
+    N = full_set_size or Z.shape[0]
+    M_, Kb = Z.shape[0], X.shape[0]
+    beta, gamma = N / M_, N / Kb
+    engz, Wm = _factor_of(state, Z, model_type)
+    _, Wx = _factor_of(state, X, model_type)
+    dev, D = Wm.device, engz.D
+    d, dx = Wm.shape[0], Wx.shape[0]
+    Gd = gram_from_factor(Wm); Gd = 0.5 * (Gd + Gd.T)
+    Gx = gram_from_factor(Wx); Gx = 0.5 * (Gx + Gx.T)
+    Gxz = _gram64(Wx, Wm)
+    lam, U = torch.linalg.eigh(Gd)
+    lam = lam.clamp_min(0.0)
+    # (S - S_z) Wm^T, row form:  [alpha^-1 I - C] Wm - alpha^-1 B^T Wx,   B = (alpha/gamma I + Gx)^-1 Gxz
+    E = (U * (beta * lam / (alpha * (alpha + beta * lam)))) @ U.T           # alpha^-1 I - (alpha I + beta Gd)^-1
+    Ix = torch.eye(dx, device=dev, dtype=torch.float64)
+    B = torch.linalg.solve(alpha / gamma * Ix + Gx, Gxz)
+    Mrow = (E.float() @ Wm).addmm_(B.T.float(), Wx, beta=1.0, alpha=-1.0 / alpha)
+    gZ = 2.0 * beta * _input_grad_of_pairing(state, Z, Mrow, model_type)
+    # value: tr(S P_z) - log det P_z,  tr(S P_z) = alpha tr S + beta tr(Wm S Wm^T)
+    tr_S = (D - torch.trace(torch.linalg.solve(alpha / gamma * Ix + Gx, Gx))) / alpha
+    tr_WSW = (torch.trace(Gd) - (Gxz * B).sum()) / alpha
+    logdet_Pz = torch.log1p(beta / alpha * lam).sum() + D * math.log(alpha)
+    loss = float(alpha * tr_S + beta * tr_WSW - logdet_Pz)
+    return loss, gZ.reshape(Z.shape).to(Z.dtype)
+
+
+def optimize_step(Z, X, map_model_state, alpha, opt_state, rng, zoptimizer, num_mc_samples=None, model_type="classifier",
+                  full_set_size=None, scalable=True, **kw):
+    """``src/train_inducing.py:199-232``: one optimiser step on Z.  ``zoptimizer`` is any object with
+    ``update(grads, opt_state, params) -> (updates, new_opt_state)`` (the optax protocol; :class:`AdamW` below)."""
+    fn = variational_grad_scalable if scalable else variational_grad_dense
+    loss, grads = fn(Z, X, map_model_state, alpha, key=rng, model_type=model_type, full_set_size=full_set_size, **kw)
+    updates, new_opt_state = zoptimizer.update(grads, opt_state, Z)
+    return Z + updates, new_opt_state, loss
+
+
+class AdamW:
+    """optax.adamw(lr, weight_decay) as used by the reference's inducing-point scripts."""
+
+    def __init__(self, lr=1e-2, b1=0.9, b2=0.999, eps=1e-8, weight_decay=1e-4):
+        self.lr, self.b1, self.b2, self.eps, self.wd = lr, b1, b2, eps, weight_decay
+
+    def init(self, params):
+        return dict(t=0, m=torch.zeros_like(params), v=torch.zeros_like(params))
+
+    def update(self, grads, st, params):
+        t = st["t"] + 1
+        m = self.b1 * st["m"] + (1 - self.b1) * grads
+        v = self.b2 * st["v"] + (1 - self.b2) * grads * grads
+        mh, vh = m / (1 - self.b1 ** t), v / (1 - self.b2 ** t)
+        upd = -self.lr * (mh / (vh.sqrt() + self.eps) + self.wd * params)
+        return upd, dict(t=t, m=m, v=v)
+
+
+def train_inducing_points(map_model_state, zinit, zoptimizer, batches, model_type, rng=0, num_mc_samples=None, alpha=1.0,
+                          num_steps=100, full_set_size=None, scalable=True, **kw):
+    """``src/train_inducing.py:235-...`` without the plotting: ``batches`` is an iterable (re-iterated when exhausted)
+    of data batches X (or (X, y) pairs).  Returns ``(Z, losses)``."""
+    z = zinit.clone()
+    opt_state = zoptimizer.init(z)
+    it = iter(batches)
+    losses = []
+    for step in range(num_steps):
+        try:
+            b = next(it)
+        except StopIteration:
+            it = iter(batches)
+            b = next(it)
+        Xb = b[0] if isinstance(b, (tuple, list)) else b
+        z, opt_state, loss = optimize_step(z, Xb, map_model_state, alpha, opt_state, rng + step, zoptimizer, num_mc_samples,
+                                           model_type, full_set_size, scalable, **kw)
+        losses.append(loss)
+    return z, losses

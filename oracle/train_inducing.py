@@ -45,3 +45,53 @@ def alternative_objective_scalable(Z, X, state, alpha, model_type, probes, full_
     quad = integrand_funm_product_logdet(bidiag(k))
     logdet_term = torch.stack([quad(A, AT, p) for p in probes[:slq_samples]]).mean()
     return float(logdet_term + trace_term), float(logdet_term), float(trace_term)
+
+
+# ---- gradients w.r.t. Z: ``jax.value_and_grad`` of the objectives (``src/train_inducing.py:195-196``) -------------
+def _ggn_dense_t(state, Z, model_type, N):
+    """``src/ggn.py:149-193`` kept differentiable in Z (``torch.func.jacrev`` per example)."""
+    from torch.func import jacrev
+    from .ggn import _model_fun
+    flat, unravel = flatten_nn_params(state.params)
+    f = _model_fun(state, unravel, model_type)
+    M = Z.shape[0]
+    G = torch.zeros(flat.numel(), flat.numel(), dtype=flat.dtype)
+    for i in range(M):
+        J = jacrev(lambda p: f(p, Z[i]).reshape(-1))(flat)
+        if model_type == "classifier":
+            pr = torch.softmax(f(flat, Z[i]).reshape(-1), dim=-1)
+            G = G + J.T @ (torch.diag(pr) - torch.outer(pr, pr)) @ J
+        else:
+            G = G + J.T @ J
+    if model_type == "regressor":
+        G = G * torch.exp(-state.params["logvar"]["logvar"]).reshape(())
+    return G * (N / M)
+
+
+def objective_dense_t(Z, X, state, alpha, model_type, full_set_size):
+    """``alternative_objective_dense`` (``:176-193``) as a differentiable torch scalar: tr(S P_z) - log det P_z."""
+    N = full_set_size
+    D = flatten_nn_params(state.params)[0].numel()
+    I = torch.eye(D, dtype=Z.dtype)
+    P = _ggn_dense_t(state, X, model_type, N).detach() + alpha * I
+    Pz = _ggn_dense_t(state, Z, model_type, N) + alpha * I
+    return torch.trace(torch.linalg.solve(P, Pz)) - torch.linalg.slogdet(Pz)[1]
+
+
+def objective_scalable_t(Z, X, state, alpha, model_type, full_set_size):
+    """What ``alternative_objective_scalable`` / ``_exact`` (``:26-173``) estimate, up to Z-independent constants:
+    tr(P S_z) + log det P_z  (``S_vp`` there is the data PRECISION, ``Sz_inv_vp_woodbury_dense`` the covariance S_z)."""
+    N = full_set_size
+    D = flatten_nn_params(state.params)[0].numel()
+    I = torch.eye(D, dtype=Z.dtype)
+    P = _ggn_dense_t(state, X, model_type, N).detach() + alpha * I
+    Pz = _ggn_dense_t(state, Z, model_type, N) + alpha * I
+    return torch.trace(torch.linalg.solve(Pz, P)) + torch.linalg.slogdet(Pz)[1]
+
+
+def variational_grad(objective, Z, X, state, alpha, model_type, full_set_size):
+    """(value, d value / dZ) by reverse mode through the dense construction — what ``jax.value_and_grad`` returns."""
+    Zr = Z.clone().requires_grad_(True)
+    val = objective(Zr, X, state, alpha, model_type, full_set_size)
+    g, = torch.autograd.grad(val, Zr)
+    return float(val.detach()), g

@@ -1,4 +1,4 @@
-"""Per-op timing of the CIFAR ResNet1M sweep (each IGEMM / WGRAD op of the tangent and backward tapes timed alone
+"""Per-op timing of the CIFAR ResNet1M sweep (or, with argument `resnet50`, of the full-resolution ResNet-50 slice) (each IGEMM / WGRAD op of the tangent and backward tapes timed alone
 with events through lip_debug_run_ops): which layer shapes sit furthest from the MFMA roof."""
 import sys, torch
 sys.path.insert(0, '.')
@@ -8,9 +8,15 @@ from lip_amd.engine import LinearizedNet
 from lip_amd.scalemodels import ResNet1M
 from lip_amd.toymodels import create_state
 
-P = 256
-net = ResNet1M(10); st = create_state(net, seed=1, dtype=torch.float32)
-eng = LinearizedNet(st, torch.rand(50, 32, 32, 3).cuda(), "classifier", workspace_bytes=24 << 30, max_chunk=P)
+if len(sys.argv) > 1 and sys.argv[1] == "resnet50":
+    from lip_amd.scalemodels import ResNet50
+    P = 64
+    net = ResNet50(1000); st = create_state(net, seed=1, dtype=torch.float32)
+    eng = LinearizedNet(st, torch.rand(8, 224, 224, 3).cuda(), "classifier", workspace_bytes=64 << 30, max_chunk=P)
+else:
+    P = 256
+    net = ResNet1M(10); st = create_state(net, seed=1, dtype=torch.float32)
+    eng = LinearizedNet(st, torch.rand(50, 32, 32, 3).cuda(), "classifier", workspace_bytes=24 << 30, max_chunk=P)
 V = krylov.fill_rademacher(P, eng.D, 1, "cuda")
 Y = torch.zeros(P, eng.D, device="cuda"); H = torch.zeros(P, eng.n * eng.K, device="cuda")
 eng.ggn_vp(V, 1.0, 0.0); torch.cuda.synchronize()
