@@ -150,6 +150,25 @@ def test_factor_rows_per_example_equal_one_hot_sweeps():
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item(), name
 
 
+def test_edge_sizes_single_example_single_probe_and_empty_block():
+    """n = 1 example, P = 1 probe (split-K weight gradient path), and an empty probe block (a clean error, no launch)."""
+    net = ResNet1M(5, input_shape=(8, 8, 3), widths=(16, 32), blocks_per_stage=1)
+    st = create_state(net, 2, dtype=F64)
+    Z = torch.rand(1, 8, 8, 3, dtype=F64, generator=torch.Generator().manual_seed(1))
+    eng = LinearizedNet(st, Z, "classifier")
+    flat, _ = flatten_nn_params(st.params)
+    tm = TapeMachine(eng.cn, flat, build_consts(eng.cn, st.params, st.batch_stats, "cpu", F64), Z, chunk=1)
+    tm.primal()
+    v = torch.randn(1, eng.D, dtype=F64, generator=torch.Generator().manual_seed(2))
+    y = eng.ggn_vp(v, 3.0, 0.2)
+    torch.cuda.synchronize()
+    assert _rel(y, tm.ggn_vp(v, 3.0, 0.2)) <= 2e-4
+    rows = eng.vjp_rows(torch.ones(1, 1, eng.K), "l", 1.0)
+    assert rows.shape == (1, 1, eng.D) and _rel(rows[:, 0], eng.vjp(torch.ones(1, 1, eng.K), "l", 1.0).double().cpu()) <= 1e-5
+    with pytest.raises((nv.NativeError, ValueError, RuntimeError)):
+        eng.ggn_vp(torch.zeros(0, eng.D), 1.0, 0.0)
+
+
 def test_missing_netspec_fails_loudly():
     from lip_amd.utils import TrainState
     st = TrainState(params={"params": {"W": torch.ones(1, 1)}}, apply_fn=lambda p, x, **k: x)
