@@ -48,14 +48,15 @@ def _seed(key) -> int:
 GRAM_RTOL = 1e-6
 
 
-def _psd_and_pinv(G: torch.Tensor, rtol: float = GRAM_RTOL):
+def _psd_and_pinv(G: torch.Tensor, rtol: float = GRAM_RTOL, return_eig: bool = False):
     """Project the symmetric Gram matrix onto the PSD cone and return (G_psd, G^+) in float64.
     Eigenvalues <= rtol * max are treated as zero (the classifier's W^T W has rank M (K-1))."""
     ev, U = torch.linalg.eigh(G.double())
     keep = ev > rtol * ev.max().clamp_min(1e-300)
     evp = torch.where(keep, ev, torch.zeros_like(ev))
     inv = torch.where(keep, 1.0 / ev.clamp_min(1e-300), torch.zeros_like(ev))
-    return (U * evp) @ U.T, (U * inv) @ U.T
+    out = ((U * evp) @ U.T, (U * inv) @ U.T)
+    return out + (evp, U) if return_eig else out
 
 
 def _pinv_sym(G: torch.Tensor, rtol: float = GRAM_RTOL) -> torch.Tensor:
@@ -84,7 +85,7 @@ class _SamplerParts:
             G64 = torch.triu(G64) + torch.triu(G64, 1).T                                                 # :227
         else:
             G64 = build_WTW(self.Wfun, self.WTfun, self.inner, self.d, dtype=torch.float64, block=2)    # :77
-        G_psd, G_pinv = _psd_and_pinv(G64)
+        G_psd, G_pinv, evp, Ug = _psd_and_pinv(G64, return_eig=True)
         self.WTW = G_psd.float().contiguous()
         self.G_pinv = G_pinv.float().contiguous()
         A64 = self.alpha * torch.eye(self.d, device=eng.device, dtype=torch.float64) + self.beta * G_psd
@@ -95,7 +96,11 @@ class _SamplerParts:
         if method == "lanczos":
             self.funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(f, clip_min, floor=self.alpha), self.depth)   # :113-115
         elif method == "eigh":
-            self.fA = krylov.dense_funm_sym_eigh(f, clip_min, floor=self.alpha)(A64).float().contiguous()
+            # alpha I + beta G_psd shares G_psd's eigenvectors: f(A) from the decomposition already at hand
+            lamA = torch.clamp(self.alpha + self.beta * evp, min=self.alpha)
+            if clip_min is not None:
+                lamA = torch.clamp(lamA, min=clip_min)
+            self.fA = ((Ug * f(lamA)) @ Ug.T).float().contiguous()
         else:
             raise ValueError("method must be 'lanczos' or 'eigh'")
 

@@ -186,7 +186,7 @@ def _input_grad_of_pairing(state, Z, Mrow, model_type):
 
 
 def variational_grad_scalable(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None,
-                              x_chunk: Optional[int] = None, **_):
+                              x_chunk: Optional[int] = None, _with_constants: bool = False, **_):
     """``jax.value_and_grad(alternative_objective_scalable)`` (``src/train_inducing.py:196``) -> ``(loss, dLoss/dZ)``.
 
     The objective is F(Z) = tr(P S_z) + log det P_z  (P = alpha I + gamma G_X the data precision, S_z = P_z^-1), the
@@ -214,6 +214,7 @@ def variational_grad_scalable(Z, X, state, alpha, key=None, model_type="classifi
     for s0 in range(0, Kb, step):
         Xc = X[s0:s0 + step]
         _, Wx = _factor_of(state, Xc, model_type)
+        tr_x += float((Wx.double() ** 2).sum()) if _with_constants else 0.0
         Gxz = _gram64(Wx, Wm)                                               # (dx_c, d)
         H += Gxz.T @ Gxz
         A2 = (gamma / alpha) * (Gxz @ C)                                    # (dx_c, d)
@@ -229,37 +230,18 @@ def variational_grad_scalable(Z, X, state, alpha, key=None, model_type="classifi
     trace1 = (Minv * Gd).sum()
     trace2 = (Minv * H).sum()
     loss = float(logdet_term - a_inv * trace1 - gamma * a_inv ** 2 * trace2)
+    if _with_constants:                       # the two Z-independent terms the exact twin drops (:69, :80-82)
+        loss += D + gamma * a_inv * tr_x
     return loss, gZ.reshape(Z.shape).to(Z.dtype)
 
 
-def variational_grad_dense(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None, **_):
-    """``jax.value_and_grad(alternative_objective_dense)`` (``src/train_inducing.py:195``): F(Z) = tr(S P_z) - log det
-    P_z with S = (alpha I + gamma G_X)^-1.  Frozen factor Q = S - S_z; S W through Woodbury on the data factor."""
-    from .ggn import gram_from_factor
-    N = full_set_size or Z.shape[0]
-    M_, Kb = Z.shape[0], X.shape[0]
-    beta, gamma = N / M_, N / Kb
-    engz, Wm = _factor_of(state, Z, model_type)
-    _, Wx = _factor_of(state, X, model_type)
-    dev, D = Wm.device, engz.D
-    d, dx = Wm.shape[0], Wx.shape[0]
-    Gd = gram_from_factor(Wm); Gd = 0.5 * (Gd + Gd.T)
-    Gx = gram_from_factor(Wx); Gx = 0.5 * (Gx + Gx.T)
-    Gxz = _gram64(Wx, Wm)
-    lam, U = torch.linalg.eigh(Gd)
-    lam = lam.clamp_min(0.0)
-    # (S - S_z) Wm^T, row form:  [alpha^-1 I - C] Wm - alpha^-1 B^T Wx,   B = (alpha/gamma I + Gx)^-1 Gxz
-    E = (U * (beta * lam / (alpha * (alpha + beta * lam)))) @ U.T           # alpha^-1 I - (alpha I + beta Gd)^-1
-    Ix = torch.eye(dx, device=dev, dtype=torch.float64)
-    B = torch.linalg.solve(alpha / gamma * Ix + Gx, Gxz)
-    Mrow = (E.float() @ Wm).addmm_(B.T.float(), Wx, beta=1.0, alpha=-1.0 / alpha)
-    gZ = 2.0 * beta * _input_grad_of_pairing(state, Z, Mrow, model_type)
-    # value: tr(S P_z) - log det P_z,  tr(S P_z) = alpha tr S + beta tr(Wm S Wm^T)
-    tr_S = (D - torch.trace(torch.linalg.solve(alpha / gamma * Ix + Gx, Gx))) / alpha
-    tr_WSW = (torch.trace(Gd) - (Gxz * B).sum()) / alpha
-    logdet_Pz = torch.log1p(beta / alpha * lam).sum() + D * math.log(alpha)
-    loss = float(alpha * tr_S + beta * tr_WSW - logdet_Pz)
-    return loss, gZ.reshape(Z.shape).to(Z.dtype)
+def variational_grad_dense(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None, **kw):
+    """``jax.value_and_grad(alternative_objective_dense)`` (``src/train_inducing.py:195``).  In that function ``S`` and
+    ``S_z`` are the PRECISIONS returned by ``compute_curvature_approx_dense`` (``:181-183``), so the value is
+    tr(P P_z^-1) + log det P_z — the same function of Z as the scalable objective plus the two constants that one
+    drops.  Nothing D x D is formed here: same factor algebra, constants added back."""
+    return variational_grad_scalable(Z, X, state, alpha, key=key, model_type=model_type, full_set_size=full_set_size,
+                                     _with_constants=True, **kw)
 
 
 def optimize_step(Z, X, map_model_state, alpha, opt_state, rng, zoptimizer, num_mc_samples=None, model_type="classifier",

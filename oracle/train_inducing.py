@@ -69,24 +69,27 @@ def _ggn_dense_t(state, Z, model_type, N):
 
 
 def objective_dense_t(Z, X, state, alpha, model_type, full_set_size):
-    """``alternative_objective_dense`` (``:176-193``) as a differentiable torch scalar: tr(S P_z) - log det P_z."""
+    """``alternative_objective_dense`` (``:176-193``) as a differentiable torch scalar.  ``S`` / ``S_z`` there are what
+    ``compute_curvature_approx_dense`` returns — the precisions GGN + alpha I — so the value is
+    tr(P inv(P_z)) - log det inv(P_z) = tr(P P_z^-1) + log det P_z."""
     N = full_set_size
     D = flatten_nn_params(state.params)[0].numel()
     I = torch.eye(D, dtype=Z.dtype)
-    P = _ggn_dense_t(state, X, model_type, N).detach() + alpha * I
-    Pz = _ggn_dense_t(state, Z, model_type, N) + alpha * I
-    return torch.trace(torch.linalg.solve(P, Pz)) - torch.linalg.slogdet(Pz)[1]
+    S = _ggn_dense_t(state, X, model_type, N).detach() + alpha * I
+    S_z = _ggn_dense_t(state, Z, model_type, N) + alpha * I
+    S_z_inv = torch.linalg.inv(S_z)
+    trace_term = torch.trace(S @ S_z_inv)
+    logdet_term = -torch.linalg.slogdet(S_z_inv)[1]
+    return logdet_term + trace_term
 
 
 def objective_scalable_t(Z, X, state, alpha, model_type, full_set_size):
-    """What ``alternative_objective_scalable`` / ``_exact`` (``:26-173``) estimate, up to Z-independent constants:
-    tr(P S_z) + log det P_z  (``S_vp`` there is the data PRECISION, ``Sz_inv_vp_woodbury_dense`` the covariance S_z)."""
-    N = full_set_size
+    """What ``alternative_objective_scalable`` estimates and ``_exact`` (``:26-84``) evaluates: the dense objective
+    minus its two Z-independent terms D and (gamma/alpha) tr(G_X at N/M = 1) (dropped at ``:69`` and ``:80-82``)."""
+    N, Kb = full_set_size, X.shape[0]
     D = flatten_nn_params(state.params)[0].numel()
-    I = torch.eye(D, dtype=Z.dtype)
-    P = _ggn_dense_t(state, X, model_type, N).detach() + alpha * I
-    Pz = _ggn_dense_t(state, Z, model_type, N) + alpha * I
-    return torch.trace(torch.linalg.solve(Pz, P)) + torch.linalg.slogdet(Pz)[1]
+    GX = _ggn_dense_t(state, X, model_type, N).detach() * (Kb / N)          # sum over the batch, no recalibration
+    return objective_dense_t(Z, X, state, alpha, model_type, full_set_size) - D - (N / Kb) / alpha * torch.trace(GX)
 
 
 def variational_grad(objective, Z, X, state, alpha, model_type, full_set_size):

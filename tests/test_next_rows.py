@@ -146,5 +146,7 @@ def test_inducing_objective_values_hip(classification_2d_data, classifier_state)
     trWW = float(torch.trace(hg.build_WTW(W, WT, WT.out_shape, 10, dtype=torch.float64, block=1)))
     const = D + (N / Xb.shape[0]) / alpha * trWW
     assert abs((ex + const) - de) <= 2e-3 * abs(de), (ex + const, de)
-    with pytest.raises(NotImplementedError):
-        ti.optimize_step()
+    # value_and_grad twins return the same values (gradients: tests/test_train_inducing_grad.py)
+    vs, _ = ti.variational_grad_scalable(Z.cuda().float(), Xb.cuda().float(), st, alpha, model_type="classifier", full_set_size=N)
+    vd, _ = ti.variational_grad_dense(Z.cuda().float(), Xb.cuda().float(), st, alpha, model_type="classifier", full_set_size=N)
+    assert abs(vs - ex) <= 1e-4 * max(1.0, abs(ex)) and abs(vd - de) <= 2e-3 * abs(de)

@@ -48,6 +48,7 @@ def test_variational_grads_match_oracle(name):
         assert g.shape == Z.shape
         # float32 factors / float64 small algebra; tolerance 2e-3 of the gradient's scale
         assert (g - g_o).abs().max().item() <= 2e-3 * g_o.abs().max().item(), (name, fn.__name__, (g - g_o).abs().max().item(), g_o.abs().max().item())
+        assert abs(v - v_o) <= 2e-3 * max(1.0, abs(v_o)), (name, fn.__name__, v, v_o)
     # chunked data batch gives the same gradient
     v2, g2 = variational_grad_scalable(Z.cuda(), X.cuda(), st, alpha, key=0, model_type=mt, full_set_size=N, x_chunk=2)
     assert (g2.double().cpu() - g_o).abs().max().item() <= 2e-3 * g_o.abs().max().item()
