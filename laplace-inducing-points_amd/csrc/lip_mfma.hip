@@ -440,10 +440,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 //   once (branch-free, host-precomputed segment scalars) and reused for the C/16 K-tiles of the tap;
 //   B and LDS offsets are loop invariant.  ~8 non-MFMA instructions per MFMA instead of ~30.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool SPLIT = false, bool PAR = false>
+// BV4: the B operand (weights, [K][N] with N contiguous) is read four channels at a time — global_load_dwordx4 needs
+// only dword alignment (the per-probe rows of V are not 16-byte aligned), so N % 4 == 0 is the only condition.
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int WM, int WN, int TM, int TN, bool SPLIT = false, bool PAR = false, bool BV4 = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
   using T = Tile<WM, WN, TM, TN>;
-  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ, BE = T::BE;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;
+  constexpr int BQ = (BN * BK / 4 + NT - 1) / NT;            // BV4: float4 per thread per K-tile
+  constexpr bool BQPART = (BN * BK / 4) % NT != 0;           // (the 32-wide tile: only half the threads load B)
+  constexpr int BE = BV4 ? 4 * BQ : T::BE;
+  constexpr int NB = BV4 ? BQ : T::BE;                       // B load instructions per thread per K-tile
   constexpr int LDA = BM + 2, LDB = BN;
   constexpr int ASZ = SPLIT ? 2 * BM * SROW : BK * LDA;      // floats per LDS buffer
   constexpr int BSZ = SPLIT ? 2 * BN * SROW : BK * LDB;
@@ -495,14 +503,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
     }
   }
   // loop-invariant B element offsets: e = tid + j*NT -> (k = e / BN, nn = e % BN)
-  unsigned bidx[BE];
-  bool bok[BE];
+  unsigned bidx[NB];
+  bool bok[NB];
 #pragma unroll
-  for (int j = 0; j < BE; ++j) {
+  for (int j = 0; j < NB; ++j) {
     const int e = tid + j * NT;
-    const int k = e / BN, nn = e - k * BN;
-    bok[j] = (n0 + nn) < N;
-    bidx[j] = (unsigned)(k * N + n0 + nn);
+    if (BV4) {
+      const int k = e / (BN / 4), nq = e - k * (BN / 4);
+      bok[j] = (n0 + 4 * nq) < N && (!BQPART || e < BN * BK / 4);
+      bidx[j] = (unsigned)(k * N + n0 + 4 * nq);
+    } else {
+      const int k = e / BN, nn = e - k * BN;
+      bok[j] = (n0 + nn) < N;
+      bidx[j] = (unsigned)(k * N + n0 + nn);
+    }
   }
 
   int rowoff[AQ];
@@ -557,9 +571,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
       areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
     }
 #pragma unroll
-    for (int j = 0; j < BE; ++j) {
+    for (int j = 0; j < NB; ++j) {
       const float* src = bok[j] ? (bbase + bidx[j]) : prm.zeros;
-      breg[j] = *src;
+      if (BV4) {
+        const float4u v = *reinterpret_cast<const float4u*>(src);
+        breg[4 * j + 0] = v[0]; breg[4 * j + 1] = v[1]; breg[4 * j + 2] = v[2]; breg[4 * j + 3] = v[3];
+      } else {
+        breg[j] = *src;
+      }
     }
   };
   auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
@@ -570,10 +589,18 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
         split_store4(Asb, Asb + BM * SROW, m, kq4, areg[4 * j], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
       }
 #pragma unroll
-      for (int j = 0; j < BE; ++j) {
+      for (int j = 0; j < NB; ++j) {
         const int e = tid + j * NT;
-        const int k = e / BN, nn = e - k * BN;
-        split_store1(Bsb, Bsb + BN * SROW, nn, k, breg[j]);
+        if (BV4) {
+          const int k = e / (BN / 4), nq = e - k * (BN / 4);
+          if (!BQPART || e < BN * BK / 4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) split_store1(Bsb, Bsb + BN * SROW, 4 * nq + t, k, breg[4 * j + t]);
+          }
+        } else {
+          const int k = e / BN, nn = e - k * BN;
+          split_store1(Bsb, Bsb + BN * SROW, nn, k, breg[j]);
+        }
       }
       return;
     }
@@ -584,10 +611,17 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
       for (int t = 0; t < 4; ++t) Asb[(kq4 + t) * LDA + m] = areg[4 * j + t];
     }
 #pragma unroll
-    for (int j = 0; j < BE; ++j) {
+    for (int j = 0; j < NB; ++j) {
       const int e = tid + j * NT;
-      const int k = e / BN, nn = e - k * BN;
-      Bsb[k * LDB + nn] = breg[j];
+      if (BV4) {
+        const int k = e / (BN / 4), nq = e - k * (BN / 4);
+        if (!BQPART || e < BN * BK / 4)
+          *reinterpret_cast<float4*>(&Bsb[k * LDB + 4 * nq]) =
+              make_float4(breg[4 * j + 0], breg[4 * j + 1], breg[4 * j + 2], breg[4 * j + 3]);
+      } else {
+        const int k = e / BN, nn = e - k * BN;
+        Bsb[k * LDB + nn] = breg[j];
+      }
     }
   };
   // move to the next K-tile (callers never advance past the last tile)
@@ -1048,15 +1082,25 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       any_s2 = any_s2 || (p.seg[s].mode == 1 && p.seg[s].stride == 2);
     }
     par = par && any_s2;
+    // B as dwordx4 when N % 4 == 0, on the tiles of 64+ columns (A/B switch LIP_NOBV4; measured per op at P = 256:
+    // N = 128 forward 117.5 -> 128.1 TF, N = 64 forward 111.5 -> 119, backward +2..7 %; the 32-column tile, where only
+    // half the threads would carry a B load, lost 5 % and keeps dword loads)
+    static const bool nobv4 = getenv("LIP_NOBV4") != nullptr;
+    const bool split = precision_mode() == 1;      // (split mode: 2081 -> 1820 GGN-vp/s with dwordx4 B loads — off)
+    const bool bv4 = !nobv4 && !split && (p.N & 3) == 0 && T::BN >= 64;
     if (par) {
       q.OW2 = p.OW / 2; q.OHW2 = (OH / 2) * q.OW2; q.Rc = (p.R / p.OHW) * q.OHW2;
       q.dOHW2 = FastDiv((unsigned)q.OHW2); q.dOW2 = FastDiv((unsigned)q.OW2);
       grid.x = (unsigned)(4ll * ((q.Rc + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN));
-      if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true, true>), grid, dim3(T::NT), 0, st, q);
-      else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, true>), grid, dim3(T::NT), 0, st, q);
     }
-    else if (precision_mode() == 1) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
-    else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false>), grid, dim3(T::NT), 0, st, q);
+#define LIP_LAUNCH_IGEMM(S_, P_, V_) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, S_, P_, V_>), grid, dim3(T::NT), 0, st, q)
+    if (split) {
+      if (par) LIP_LAUNCH_IGEMM(true, true, false); else LIP_LAUNCH_IGEMM(true, false, false);
+    } else {
+      if (par) { if (bv4) LIP_LAUNCH_IGEMM(false, true, true); else LIP_LAUNCH_IGEMM(false, true, false); }
+      else { if (bv4) LIP_LAUNCH_IGEMM(false, false, true); else LIP_LAUNCH_IGEMM(false, false, false); }
+    }
+#undef LIP_LAUNCH_IGEMM
     if (dbg) {
       static int reports = 0;
       if (reports < 60) {
