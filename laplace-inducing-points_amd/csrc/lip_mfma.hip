@@ -848,13 +848,14 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
 // Thread-invariant: its kernel tap (kh, kw, ci) and LDS / B offsets.  Per 16-row K-step each float4
 // gather costs two magic-number divisions + a branch-free bounds test.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool PB = false>
+template <int WM, int WN, int TM, int TN, bool PB = false, bool BV4 = PB>
 __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP prm) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;
-  constexpr int BQ = (BN * BK / 4 + NT - 1) / NT;          // PB: B float4 per thread per K-tile
+  static_assert(!PB || BV4, "the probe-batched variant reads the cotangent as float4");
+  constexpr int BQ = (BN * BK / 4 + NT - 1) / NT;          // BV4: B float4 per thread per K-tile
   constexpr bool BQPART = (BN * BK / 4) % NT != 0;
-  constexpr int BE = PB ? 4 * BQ : T::BE;
+  constexpr int BE = BV4 ? 4 * BQ : T::BE;
   constexpr int LDA = BM + 4, LDB = BN;
   constexpr int QPR = BM / 4;
   __shared__ __attribute__((aligned(16))) float As[2 * BK * LDA];
@@ -898,18 +899,18 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     tww = kw - prm.pad_w;
   }
   const int krow0 = tid / QPR;                    // row of quad j inside the K-step: krow0 + j*(NT/QPR)
-  constexpr int NB = PB ? BQ : BE;                // B load instructions per thread per K-tile
+  constexpr int NB = BV4 ? BQ : BE;               // B load instructions per thread per K-tile
   unsigned bidx[NB];
   int bk[NB];
   bool bok[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int e = tid + j * NT;
-    if (PB) {                                     // float4 along the channels of one probe (N % 4 == 0)
+    if (BV4) {                                    // float4 along the channels of one probe (N % 4 == 0)
       const int k = e / (BN / 4), nq = e - k * (BN / 4);
       bk[j] = k;
       bok[j] = (n0 + 4 * nq) < NC && (!BQPART || e < BN * BK / 4);
-      const int jc = bok[j] ? n0 + 4 * nq : 0, pj = jc / N;
+      const int jc = bok[j] ? n0 + 4 * nq : 0, pj = PB ? jc / N : 0;
       bidx[j] = (unsigned)((long long)pj * prm.g_ps + k * N + (jc - pj * N));     // < 2^32 floats (host-checked)
     } else {
       const int k = e / BN, nn = e - k * BN;
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float* src = (bok[j] && (rk0 + bk[j]) < rend) ? (gp + bidx[j]) : prm.zeros;
-      if (PB) {
+      if (BV4) {
         const float4 v = *reinterpret_cast<const float4*>(src);
         breg[4 * j + 0] = v.x; breg[4 * j + 1] = v.y; breg[4 * j + 2] = v.z; breg[4 * j + 3] = v.w;
       } else {
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int e = tid + j * NT;
-      if (PB) {
+      if (BV4) {
         const int k = e / (BN / 4), nq = e - k * (BN / 4);
         if (!BQPART || e < BN * BK / 4)
           *reinterpret_cast<float4*>(&Bsb[k * LDB + 4 * nq]) =
@@ -1149,7 +1150,12 @@ static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
     WgradP q = p;
     q.zeros = zero_page();
     if (!q.zeros) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q);
+    // cotangent rows as float4 on the 64+ column tiles (N % 4 == 0, 16-byte aligned slot; A/B switch LIP_NOBV4)
+    static const bool nobv4 = getenv("LIP_NOBV4") != nullptr;
+    if (!nobv4 && T::BN >= 64 && (p.N & 3) == 0 && (p.g_ps & 3) == 0 && (((uintptr_t)p.g) & 15) == 0)
+      hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false, true>), grid, dim3(T::NT), 0, st, q);
+    else
+      hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false, false>), grid, dim3(T::NT), 0, st, q);
   }
   else
     hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, p);
