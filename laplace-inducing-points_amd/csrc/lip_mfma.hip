@@ -440,18 +440,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 //   once (branch-free, host-precomputed segment scalars) and reused for the C/16 K-tiles of the tap;
 //   B and LDS offsets are loop invariant.  ~8 non-MFMA instructions per MFMA instead of ~30.
 // ------------------------------------------------------------------------------------------
-// BV4: the B operand (weights, [K][N] with N contiguous) is read four channels at a time — global_load_dwordx4 needs
-// only dword alignment (the per-probe rows of V are not 16-byte aligned), so N % 4 == 0 is the only condition.
+// BV: the B operand (weights, [K][N] with N contiguous) is read BW = min(4, floats per thread) channels at a time —
+// global_load_dwordx2/x4 need only dword alignment (the per-probe rows of V are not 16-byte aligned), so N % BW == 0
+// is the only condition.  The K loop is sensitive to the NUMBER of vector-memory instructions, not their width.
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
-template <int WM, int WN, int TM, int TN, bool SPLIT = false, bool PAR = false, bool BV4 = false>
+template <int WM, int WN, int TM, int TN, bool SPLIT = false, bool PAR = false, bool BV = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;
-  constexpr int BQ = (BN * BK / 4 + NT - 1) / NT;            // BV4: float4 per thread per K-tile
-  constexpr bool BQPART = (BN * BK / 4) % NT != 0;           // (the 32-wide tile: only half the threads load B)
-  constexpr int BE = BV4 ? 4 * BQ : T::BE;
-  constexpr int NB = BV4 ? BQ : T::BE;                       // B load instructions per thread per K-tile
+  constexpr int BE = T::BE;                                  // B floats per thread per K-tile (2, 4 or 8)
+  constexpr int BW = BV ? (BE >= 4 ? 4 : BE) : 1;            // floats per B load instruction
+  constexpr int NB = BE / BW;                                // B load instructions per thread per K-tile
+  static_assert(!T::BPART && BE % BW == 0 && BN % BW == 0, "B vector loads need an even split");
   constexpr int LDA = BM + 2, LDB = BN;
   constexpr int ASZ = SPLIT ? 2 * BM * SROW : BK * LDA;      // floats per LDS buffer
   constexpr int BSZ = SPLIT ? 2 * BN * SROW : BK * LDB;
@@ -508,10 +510,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int e = tid + j * NT;
-    if (BV4) {
-      const int k = e / (BN / 4), nq = e - k * (BN / 4);
-      bok[j] = (n0 + 4 * nq) < N && (!BQPART || e < BN * BK / 4);
-      bidx[j] = (unsigned)(k * N + n0 + 4 * nq);
+    if (BW > 1) {
+      const int k = e / (BN / BW), nq = e - k * (BN / BW);
+      bok[j] = (n0 + BW * nq) < N;
+      bidx[j] = (unsigned)(k * N + n0 + BW * nq);
     } else {
       const int k = e / BN, nn = e - k * BN;
       bok[j] = (n0 + nn) < N;
@@ -573,9 +575,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float* src = bok[j] ? (bbase + bidx[j]) : prm.zeros;
-      if (BV4) {
+      if (BW == 4) {
         const float4u v = *reinterpret_cast<const float4u*>(src);
         breg[4 * j + 0] = v[0]; breg[4 * j + 1] = v[1]; breg[4 * j + 2] = v[2]; breg[4 * j + 3] = v[3];
+      } else if (BW == 2) {
+        const float2u v = *reinterpret_cast<const float2u*>(src);
+        breg[2 * j + 0] = v[0]; breg[2 * j + 1] = v[1];
       } else {
         breg[j] = *src;
       }
@@ -591,12 +596,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int e = tid + j * NT;
-        if (BV4) {
-          const int k = e / (BN / 4), nq = e - k * (BN / 4);
-          if (!BQPART || e < BN * BK / 4) {
+        if (BW > 1) {
+          const int k = e / (BN / BW), nq = e - k * (BN / BW);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) split_store1(Bsb, Bsb + BN * SROW, 4 * nq + t, k, breg[4 * j + t]);
-          }
+          for (int t = 0; t < BW; ++t) split_store1(Bsb, Bsb + BN * SROW, BW * nq + t, k, breg[BW * j + t]);
         } else {
           const int k = e / BN, nn = e - k * BN;
           split_store1(Bsb, Bsb + BN * SROW, nn, k, breg[j]);
@@ -613,11 +616,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int e = tid + j * NT;
-      if (BV4) {
+      if (BW == 4) {
         const int k = e / (BN / 4), nq = e - k * (BN / 4);
-        if (!BQPART || e < BN * BK / 4)
-          *reinterpret_cast<float4*>(&Bsb[k * LDB + 4 * nq]) =
-              make_float4(breg[4 * j + 0], breg[4 * j + 1], breg[4 * j + 2], breg[4 * j + 3]);
+        *reinterpret_cast<float4*>(&Bsb[k * LDB + 4 * nq]) =
+            make_float4(breg[4 * j + 0], breg[4 * j + 1], breg[4 * j + 2], breg[4 * j + 3]);
+      } else if (BW == 2) {
+        const int k = e / (BN / 2), nq = e - k * (BN / 2);
+        *reinterpret_cast<float2*>(&Bsb[k * LDB + 2 * nq]) = make_float2(breg[2 * j + 0], breg[2 * j + 1]);
       } else {
         const int k = e / BN, nn = e - k * BN;
         Bsb[k * LDB + nn] = breg[j];
@@ -1088,7 +1093,7 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
     // half the threads would carry a B load, lost 5 % and keeps dword loads)
     static const bool nobv4 = getenv("LIP_NOBV4") != nullptr;
     const bool split = precision_mode() == 1;      // (split mode: 2081 -> 1820 GGN-vp/s with dwordx4 B loads — off)
-    const bool bv4 = !nobv4 && !split && (p.N & 3) == 0 && T::BN >= 64;
+    const bool bv4 = !nobv4 && !split && (p.N & 3) == 0;
     if (par) {
       q.OW2 = p.OW / 2; q.OHW2 = (OH / 2) * q.OW2; q.Rc = (p.R / p.OHW) * q.OHW2;
       q.dOHW2 = FastDiv((unsigned)q.OHW2); q.dOW2 = FastDiv((unsigned)q.OW2);
