@@ -62,6 +62,30 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ As, const f
   }
 }
 
+// m-major A image of the f32 implicit-GEMM kernel: rows of the 16 k-values of one m, padded to LDK = 20 floats — one
+// ds_write_b128 per gathered float4 instead of a 4-dword transposing scatter; the operand reads (ds_read_b32, lane
+// stride LDK) are 2-way bank conflicted, which the K loop does not notice (measured: +1..3 % per op over the k-major
+// image).
+template <int WM, int WN, int TM, int TN, int LDK, int LDB>
+__device__ __forceinline__ void mfma_sweep_mmajor(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                  f32x16 (&acc)[TM][TN], int wm, int wn, int lane) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK / 2; ++kk) {
+    const int krow = 2 * kk + lh;
+    float a[TM], b[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[tm] = As[((wm * TM + tm) * 32 + l31) * LDK + krow];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[krow * LDB + (wn * TN + tn) * 32 + l31];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Split-precision ("bf16x3") operand path: every f32 operand x is stored in LDS as two bf16 planes,
 // hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|), and a 16-deep K-tile of a 32x32 tile is
@@ -455,7 +479,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   constexpr int NB = BE / BW;                                // B load instructions per thread per K-tile
   static_assert(!T::BPART && BE % BW == 0 && BN % BW == 0, "B vector loads need an even split");
   constexpr int LDA = BM + 2, LDB = BN;
-  constexpr int ASZ = SPLIT ? 2 * BM * SROW : BK * LDA;      // floats per LDS buffer
+  constexpr int LDK = 20;
+  constexpr bool MMAJ = !SPLIT;
+  constexpr int ASZ = SPLIT ? 2 * BM * SROW : (MMAJ ? BM * LDK : BK * LDA);      // floats per LDS buffer
   constexpr int BSZ = SPLIT ? 2 * BN * SROW : BK * LDB;
   __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
   __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
@@ -610,8 +636,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
       const int m = (tid + j * NT) >> 2;
+      if (MMAJ) {
+        *reinterpret_cast<float4*>(&Asb[m * LDK + kq4]) = make_float4(areg[4 * j], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) Asb[(kq4 + t) * LDA + m] = areg[4 * j + t];
+        for (int t = 0; t < 4; ++t) Asb[(kq4 + t) * LDA + m] = areg[4 * j + t];
+      }
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -670,6 +700,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
         ktiles, As, Bs, load_tile, store_tile, advance,
         [&](const float* Asb, const float* Bsb) {
           if (SPLIT) mfma_sweep_split<WM, WN, TM, TN>(Asb, Bsb, acc, wm, wn, lane);
+          else if (MMAJ) mfma_sweep_mmajor<WM, WN, TM, TN, LDK, LDB>(Asb, Bsb, acc, wm, wn, lane);
           else mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane);
         });
   } else {
