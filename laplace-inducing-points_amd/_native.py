@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblip_hip.so")
+LIB_PATH = os.environ.get("LIP_LIB_PATH") or os.path.join(_HERE, "csrc", "liblip_hip.so")   # env: A/B builds only
 
 LIP_OK = 0
 SP_NONE, SP_THETA, SP_CONST, SP_PRIM, SP_WORK, SP_VIN, SP_YOUT, SP_HEAD = -1, 0, 1, 2, 3, 4, 5, 6

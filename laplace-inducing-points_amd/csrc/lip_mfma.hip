@@ -62,10 +62,9 @@ __device__ __forceinline__ void mfma_sweep(const float* __restrict__ As, const f
   }
 }
 
-// m-major A image of the f32 implicit-GEMM kernel: rows of the 16 k-values of one m, padded to LDK = 20 floats — one
-// ds_write_b128 per gathered float4 instead of a 4-dword transposing scatter; the operand reads (ds_read_b32, lane
-// stride LDK) are 2-way bank conflicted, which the K loop does not notice (measured: +1..3 % per op over the k-major
-// image).
+// m-major A image (A/B build only, -DLIP_MMAJOR_A): rows of the 16 k-values of one m, padded to LDK = 20 floats — one
+// ds_write_b128 per gathered float4 instead of a 4-dword transposing scatter, 2-way bank-conflicted operand reads.
+// Measured in the same box call: 0.6 % SLOWER than the k-major image, so it is not the default.
 template <int WM, int WN, int TM, int TN, int LDK, int LDB>
 __device__ __forceinline__ void mfma_sweep_mmajor(const float* __restrict__ As, const float* __restrict__ Bs,
                                                   f32x16 (&acc)[TM][TN], int wm, int wn, int lane) {
@@ -480,7 +479,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   static_assert(!T::BPART && BE % BW == 0 && BN % BW == 0, "B vector loads need an even split");
   constexpr int LDA = BM + 2, LDB = BN;
   constexpr int LDK = 20;
-  constexpr bool MMAJ = !SPLIT;
+#ifdef LIP_MMAJOR_A
+  constexpr bool MMAJ = !SPLIT;                               // A/B build (-DLIP_MMAJOR_A): m-major A image
+#else
+  constexpr bool MMAJ = false;     // same-box A/B on MI355X: k-major 1566 vs m-major 1557 GGN-vp/s -> k-major stays
+#endif
   constexpr int ASZ = SPLIT ? 2 * BM * SROW : (MMAJ ? BM * LDK : BK * LDA);      // floats per LDS buffer
   constexpr int BSZ = SPLIT ? 2 * BN * SROW : BK * LDB;
   __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
