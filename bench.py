@@ -169,7 +169,7 @@ def main():
 
     # ---- posterior samples/s (single-rank figure; reference algorithm src/sample.py:55-156) -----------
     samples_line = None
-    if args.samples > 0 and rank == 0:
+    if args.samples > 0 and rank == 0 and world == 1:
         from lip_amd.sample import sample
         st_dev = state.to(device=dev, dtype=torch.float32)
         Zd = Z.to(dev)
@@ -302,6 +302,7 @@ def main():
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                 # rank 0 did the per-kernel profile steps after the timed region: leave together
         dist.destroy_process_group()
 
 
