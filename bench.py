@@ -219,7 +219,7 @@ def main():
         split_line = dict(value=P / t_s, unit="GGN-vp/s", ms_per_step=1e3 * t_s, dtype="bf16x3",
                           rel_diff_vs_f32=float(((Ys - Y32).abs().max() / Y32.abs().max()).item()),
                           note="opt-in lip_set_precision(1): operands split hi+lo in bf16, 3 bf16 MFMAs per product, "
-                               "f32 accumulate (igemm kernels only so far); NOT the headline: the default is exact f32")
+                               "f32 accumulate (implicit-GEMM and weight-gradient kernels); NOT the headline: the default is exact f32")
 
     # ---- opt-in materialised-factor mode (same results, two plain GEMMs; valid while d*D*4 B fits HBM) -------
     factor_line = None

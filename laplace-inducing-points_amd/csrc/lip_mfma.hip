@@ -115,6 +115,16 @@ __device__ __forceinline__ void split_store1(float* plane_hi, float* plane_lo, i
   reinterpret_cast<__bf16*>(plane_lo + row * SROW)[k] = lo;
 }
 
+// two k-adjacent values of one row (k even): the weight-gradient loaders hold rows (r, r+1) of the reduction axis
+__device__ __forceinline__ void split_store_pair(float* plane_hi, float* plane_lo, int row, int k, float x0, float x1) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 hi, lo;
+  hi[0] = (__bf16)x0; hi[1] = (__bf16)x1;
+  lo[0] = (__bf16)(x0 - (float)hi[0]); lo[1] = (__bf16)(x1 - (float)hi[1]);
+  *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(plane_hi + row * SROW) + k) = hi;
+  *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(plane_lo + row * SROW) + k) = lo;
+}
+
 // One 16-deep K-tile on the split LDS images: As = [hi plane BM rows | lo plane BM rows], Bs likewise (BN rows).
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void mfma_sweep_split(const float* __restrict__ As, const float* __restrict__ Bs,
@@ -887,18 +897,25 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
 // Thread-invariant: its kernel tap (kh, kw, ci) and LDS / B offsets.  Per 16-row K-step each float4
 // gather costs two magic-number divisions + a branch-free bounds test.
 // ------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool PB = false, bool BV4 = PB>
+template <int WM, int WN, int TM, int TN, bool PB = false, bool BV4 = PB, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP prm) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;
   static_assert(!PB || BV4, "the probe-batched variant reads the cotangent as float4");
+  static_assert(!SPLIT || (BV4 && T::AQ == 2), "split precision: float4 cotangent rows, two A quads per thread");
+  // SPLIT (bf16x3): both operands are k-contiguous bf16 rows ([m][16 k], [n][16 k]; hi and lo planes), but global
+  // memory runs along m resp. n at fixed r — each thread therefore owns the row PAIR (2 kp, 2 kp + 1) of its four
+  // channels and stores k-adjacent pairs (one ds_write_b32 per channel and plane).
   constexpr int BQ = (BN * BK / 4 + NT - 1) / NT;          // BV4: B float4 per thread per K-tile
   constexpr bool BQPART = (BN * BK / 4) % NT != 0;
-  constexpr int BE = BV4 ? 4 * BQ : T::BE;
+  constexpr int BE = SPLIT ? 8 * ((2 * T::BN + T::NT - 1) / T::NT) : (BV4 ? 4 * BQ : T::BE);
   constexpr int LDA = BM + 4, LDB = BN;
   constexpr int QPR = BM / 4;
-  __shared__ __attribute__((aligned(16))) float As[2 * BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * BK * LDB];
+  constexpr int ASZ = SPLIT ? 2 * BM * SROW : BK * LDA;      // floats per LDS buffer
+  constexpr int BSZ = SPLIT ? 2 * BN * SROW : BK * LDB;
+  constexpr int BU = SPLIT ? (2 * BN + NT - 1) / NT : 0;     // SPLIT: B units (2 rows x 4 channels) per thread
+  __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -937,15 +954,22 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     thh = kh - prm.pad_h;
     tww = kw - prm.pad_w;
   }
-  const int krow0 = tid / QPR;                    // row of quad j inside the K-step: krow0 + j*(NT/QPR)
-  constexpr int NB = BV4 ? BQ : BE;               // B load instructions per thread per K-tile
+  const int krow0 = SPLIT ? 2 * (tid / QPR) : tid / QPR;   // row of quad j inside the K-step: krow0 + j*(NT/QPR); SPLIT: krow0 + j
+  constexpr int KSTEP = SPLIT ? 1 : NT / QPR;
+  constexpr int NB = SPLIT ? BU : (BV4 ? BQ : BE);   // B units (SPLIT: 2 rows x 4 channels) / load instructions per thread
   unsigned bidx[NB];
   int bk[NB];
   bool bok[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int e = tid + j * NT;
-    if (BV4) {                                    // float4 along the channels of one probe (N % 4 == 0)
+    if (SPLIT) {                                  // unit e -> (row pair kp, channel quad nq)
+      const int kp = e / (BN / 4), nq = e - kp * (BN / 4);
+      bk[j] = 2 * kp;
+      bok[j] = (n0 + 4 * nq) < NC && e < 2 * BN;
+      const int jc = bok[j] ? n0 + 4 * nq : 0, pj = PB ? jc / N : 0;
+      bidx[j] = (unsigned)((long long)pj * prm.g_ps + 2 * kp * N + (jc - pj * N));
+    } else if (BV4) {                                    // float4 along the channels of one probe (N % 4 == 0)
       const int k = e / (BN / 4), nq = e - k * (BN / 4);
       bk[j] = k;
       bok[j] = (n0 + 4 * nq) < NC && (!BQPART || e < BN * BK / 4);
@@ -966,7 +990,7 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
   auto load_tile = [&](float (&areg)[AE], float (&breg)[BE]) {
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
-      const int r = rk0 + krow0 + j * (NT / QPR);
+      const int r = rk0 + krow0 + j * KSTEP;
       const int i = prm.dOHW.div(r), rem = r - i * OHW;
       const int oh = prm.dOW.div(rem), ow = rem - oh * OW;
       const int ih = oh * stride + thh, iw = ow * stride + tww;
@@ -977,6 +1001,15 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      if (SPLIT) {
+        const float* s0 = (bok[j] && (rk0 + bk[j]) < rend) ? (gp + bidx[j]) : prm.zeros;
+        const float* s1 = (bok[j] && (rk0 + bk[j] + 1) < rend) ? (gp + bidx[j] + N) : prm.zeros;
+        const float4 v0 = *reinterpret_cast<const float4*>(s0);
+        const float4 v1 = *reinterpret_cast<const float4*>(s1);
+        breg[8 * j + 0] = v0.x; breg[8 * j + 1] = v0.y; breg[8 * j + 2] = v0.z; breg[8 * j + 3] = v0.w;
+        breg[8 * j + 4] = v1.x; breg[8 * j + 5] = v1.y; breg[8 * j + 6] = v1.z; breg[8 * j + 7] = v1.w;
+        continue;
+      }
       const float* src = (bok[j] && (rk0 + bk[j]) < rend) ? (gp + bidx[j]) : prm.zeros;
       if (BV4) {
         const float4 v = *reinterpret_cast<const float4*>(src);
@@ -987,6 +1020,22 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     }
   };
   auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
+    if (SPLIT) {
+      const int mq = tid % QPR;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) split_store_pair(Asb, Asb + BM * SROW, 4 * mq + t, krow0, areg[t], areg[4 + t]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int e = tid + j * NT;
+        const int kp = e / (BN / 4), nq = e - kp * (BN / 4);
+        if (e < 2 * BN) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            split_store_pair(Bsb, Bsb + BN * SROW, 4 * nq + t, 2 * kp, breg[8 * j + t], breg[8 * j + 4 + t]);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
       const int q = tid + j * NT;
@@ -1014,9 +1063,12 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     gp += BK * N;
   };
   const int ktiles = (rend - rbeg + BK - 1) / BK;
-  pipelined_k_loop<AE, BE, BK * LDA, BK * LDB>(
+  pipelined_k_loop<AE, BE, ASZ, BSZ>(
       ktiles, As, Bs, load_tile, store_tile, advance,
-      [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
+      [&](const float* Asb, const float* Bsb) {
+        if (SPLIT) mfma_sweep_split<WM, WN, TM, TN>(Asb, Bsb, acc, wm, wn, lane);
+        else mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane);
+      });
 
   const int l31 = lane & 31, lh = lane >> 5;
   const long long yseg = prm.seg_rows ? (long long)blockIdx.z * prm.seg_ys : 0;
@@ -1191,7 +1243,14 @@ static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
     if (!q.zeros) return hipErrorOutOfMemory;
     // cotangent rows as float4 on the 64+ column tiles (N % 4 == 0, 16-byte aligned slot; A/B switch LIP_NOBV4)
     static const bool nobv4 = getenv("LIP_NOBV4") != nullptr;
-    if (!nobv4 && T::BN >= 64 && (p.N & 3) == 0 && (p.g_ps & 3) == 0 && (((uintptr_t)p.g) & 15) == 0)
+    const bool v4 = (p.N & 3) == 0 && (p.g_ps & 3) == 0 && (((uintptr_t)p.g) & 15) == 0;
+    if constexpr (T::AQ == 2) {
+      if (precision_mode() == 1 && v4) {              // split precision (bf16x3 operands), every tile width
+        hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false, true, true>), grid, dim3(T::NT), 0, st, q);
+        return hipGetLastError();
+      }
+    }
+    if (!nobv4 && T::BN >= 64 && v4)
       hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false, true>), grid, dim3(T::NT), 0, st, q);
     else
       hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, false, false>), grid, dim3(T::NT), 0, st, q);
@@ -1219,7 +1278,8 @@ static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
     q.ksplit = ks < 1 ? 1 : (int)ks;
   }
   dim3 grid((unsigned)tiles, 1, (unsigned)q.ksplit);
-  hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
+  if (precision_mode() == 1) hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(T::NT), 0, st, q);
+  else hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
   return hipGetLastError();
 }
 
