@@ -106,10 +106,10 @@ def main():
     n_total = n * world
     eng = LinearizedNet(state, Z.to(dev), "classifier", device=dev, workspace_bytes=24 << 30, max_chunk=P)
     scale = full / n_total
-    # alpha/world per rank sums to alpha*V in the all-reduce (no extra pass over the block); N > 1: the
-    # all-reduce of probe chunk c overlaps the sweep of chunk c+1
+    # alpha/world per rank sums to alpha*V in the all-reduce (no extra pass over the block); N > 1: the block is
+    # swept as 3/4 + 1/4 of the probes, the all-reduce of the first part hides behind the sweep of the second
     op = ShardedDataSum(lambda V, out=None: eng.ggn_vp(V, scale, alpha / world, out=out), 0.0,
-                        chunk=(max(16, P // 4) if world > 1 else None))
+                        chunk=((0.75, 0.25) if world > 1 and P >= 64 else None))
     V = krylov.fill_rademacher(P, eng.D, 1234, dev)
 
     def barrier():

@@ -162,19 +162,9 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       p.dOHW = FastDiv((unsigned)p.OHW); p.dOW = FastDiv((unsigned)p.OW);
       p.y = resolve(c, op.out); p.y_ps = op.out.pstride;
       p.scale = resolve(c, op.scale);
-      p.ksplit = op.ksplit > 0 ? op.ksplit : 1;
+      p.ksplit = op.ksplit > 0 ? op.ksplit : 0;           // 0: the launcher picks the row split for the probe count
       if (c.rows) {
         p.ksplit = op.n_img; p.seg_rows = p.OHW; p.seg_ys = p.y_ps; p.y_ps *= op.n_img;
-      } else if (op.ksplit <= 0) {
-        // few probes: split the row reduction (float atomics) so the launch still fills 256 CUs
-        const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * c.P;
-        if (tiles < 512) {
-          long long ks = (1024 + tiles - 1) / tiles;
-          const long long maxks = (p.R + 63) / 64;
-          if (ks > maxks) ks = maxks;
-          if (ks > 1024) ks = 1024;
-          p.ksplit = ks < 1 ? 1 : (int)ks;
-        }
       }
       if (!p.a || !p.g || !p.y || p.R <= 0 || p.N <= 0 || p.M <= 0) { set_error("WGRAD: bad operands"); return LIP_ERR_ARG; }
       if ((p.C & 3) == 0 && (((uintptr_t)p.a) & 15)) { set_error("WGRAD: activations not 16-byte aligned"); return LIP_ERR_ARG; }

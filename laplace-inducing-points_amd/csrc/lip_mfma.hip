@@ -1231,10 +1231,49 @@ hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st));
 }
 
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            ? pr.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+// Row split (float atomics into Y) of a weight-gradient launch with `blocks` blocks before splitting and `occ`
+// resident blocks per CU.  Blocks are long (R/16 K-tiles) and, at small probe counts, few: 640 blocks on 768 slots
+// leave a sixth of the chip idle, 1152 on 512 run a third round a quarter full.  Fill the chip when under-filled
+// and otherwise prefer a split that ends on a whole number of rounds, but only while a launch has few rounds (at
+// 256 probes the same rule measured +-0).  >= 64 K-tiles stay in every split.
+static int auto_ksplit(long long blocks, int occ, int R) {
+  const double slots = (double)cu_count() * occ;
+  const int maxks = R / (64 * BK) > 0 ? R / (64 * BK) : 1;
+  if ((double)blocks < slots) {                     // under-filled (few probes): down to 4 K-tiles per split
+    long long ks = (long long)((2.0 * slots + blocks - 1) / blocks);
+    const long long cap = R / 64 > 0 ? R / 64 : 1;
+    if (ks > cap) ks = cap;
+    if (ks > 1024) ks = 1024;
+    return (int)(ks < 1 ? 1 : ks);
+  }
+  int best = 1;
+  double best_eff = 0.0;
+  for (int ks = 1; ks <= 4 && ks <= maxks; ++ks) {
+    const double rounds = (double)blocks * ks / slots;
+    if (ks > 1 && rounds > 8.0) break;
+    const double eff = rounds / (double)(long long)(rounds + 0.999999);
+    if (eff > best_eff + 0.03) { best_eff = eff; best = ks; }
+  }
+  return best;
+}
+
 template <int WM, int WN, int TM, int TN>
-static hipError_t run_wgrad(const WgradP& p, int P, hipStream_t st) {
+static hipError_t run_wgrad(const WgradP& p0, int P, hipStream_t st) {
   using T = Tile<WM, WN, TM, TN>;
-  const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
+  const long long tiles = (long long)((p0.M + T::BM - 1) / T::BM) * ((p0.N + T::BN - 1) / T::BN);
+  WgradP p = p0;
+  if (p.ksplit <= 0) p.ksplit = auto_ksplit(tiles * P, TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4), p.R);
   dim3 grid((unsigned)tiles, (unsigned)P, (unsigned)p.ksplit);
   static const bool force_generic = getenv("LIP_GENERIC") != nullptr;     // A/B switch
   if (!force_generic && (p.C & 3) == 0 && (((uintptr_t)p.a) & 15) == 0) {
@@ -1271,10 +1310,12 @@ static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
   q.zeros = zero_page();
   if (!q.zeros) return hipErrorOutOfMemory;
   q.P = P;
-  if (p.ksplit <= 1 && !p.seg_rows) {
+  if (p.ksplit <= 0) {
     long long ks = (1536 + tiles - 1) / tiles;
-    const long long maxks = (p.R + 64 * BK - 1) / (64 * BK);        // >= 64 K-tiles per split
+    const long long maxks = tiles >= 64 ? (p.R + 64 * BK - 1) / (64 * BK)        // >= 64 K-tiles per split ...
+                                        : (p.R / 64 > 0 ? p.R / 64 : 1);          // ... 4 when there are few probes
     if (ks > maxks) ks = maxks;
+    if (ks > 1024) ks = 1024;
     q.ksplit = ks < 1 ? 1 : (int)ks;
   }
   dim3 grid((unsigned)tiles, 1, (unsigned)q.ksplit);

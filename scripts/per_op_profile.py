@@ -14,7 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "resnet50":
     net = ResNet50(1000); st = create_state(net, seed=1, dtype=torch.float32)
     eng = LinearizedNet(st, torch.rand(8, 224, 224, 3).cuda(), "classifier", workspace_bytes=64 << 30, max_chunk=P)
 else:
-    P = 256
+    P = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     net = ResNet1M(10); st = create_state(net, seed=1, dtype=torch.float32)
     eng = LinearizedNet(st, torch.rand(50, 32, 32, 3).cuda(), "classifier", workspace_bytes=24 << 30, max_chunk=P)
 V = krylov.fill_rademacher(P, eng.D, 1, "cuda")

@@ -42,6 +42,8 @@ def _worker(rank, world, port, ret):
     Y = op(V)
     Yc = ShardedDataSum(local, alpha, chunk=2)(V)          # chunked, async all-reduce per chunk
     assert torch.allclose(Y, Yc, rtol=1e-13, atol=1e-13)
+    Yf = ShardedDataSum(local, alpha, chunk=(0.75, 0.25))(V)   # uneven schedule: large first, small last chunk
+    assert torch.allclose(Y, Yf, rtol=1e-13, atol=1e-13)
     vp_full = compute_ggn_vp(st, Z, "classifier", full_set_size=N)
     ref = torch.stack([vp_full(v) + alpha * v for v in V])
     err = (Y - ref).abs().max().item()
