@@ -57,8 +57,16 @@ def cpu_baseline(net, n, seconds_budget=12.0):
 
     lit, reps_a = rate(vp_literal, min(n, 4))
     bat, reps_b = rate(vp_batched, n)
-    return dict(value=max(lit, bat), unit="GGN-vp/s", cores=torch.get_num_threads(), kind="port",
-                literal_per_example=lit, example_batched=bat,
+    cores = torch.get_num_threads()
+    bat8 = None
+    if cores > 8:                                         # also at 8 threads, comparable across hosts
+        torch.set_num_threads(8)
+        try:
+            bat8, _ = rate(vp_batched, n)
+        finally:
+            torch.set_num_threads(cores)
+    return dict(value=max(lit, bat), unit="GGN-vp/s", cores=cores, kind="port",
+                literal_per_example=lit, example_batched=bat, example_batched_at_8_threads=bat8,
                 sample=f"CPU restatement in PyTorch fp32 (not reference JAX): (a) literal per-example loop, {reps_a} x "
                        f"(1 probe x {min(n, 4)} of {n} examples) extrapolated linearly; (b) example-batched, {reps_b} x "
                        f"(1 probe x all {n} examples)")
@@ -290,13 +298,16 @@ def main():
         cpu = cpu_baseline(net, n)
 
     if rank == 0:
-        line = dict(metric="GGN-vector products/sec", value=value, unit="GGN-vp/s", n_gpus=world, steps=args.steps,
+        line = dict(metric="GGN-vector products/sec", value=value, example_probe_products_per_s=value * n, unit="GGN-vp/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload="CIFAR-CNN ResNet1M GGN-vp (BASELINE configs[3]): D=1084586, "
                                          f"n={n} examples/GPU, P={P} Rademacher probes/block, alpha=0.005, "
                                          "full_set_size=49000; data sum sharded over ranks, one all-reduce per matvec",
                                 examples_per_gpu=n, probes=P, D=eng.D, probe_chunk=eng.chunk,
+                                unit_note=f"one GGN-vp = one product over a {n}-example data block; N ranks each sweep their "
+                                          "own block for the same probes (weak scaling), value = P * N / step time; "
+                                          "example_probe_products_per_s = value * examples",
                                 parallelism=f"data-shard x{world}"),
                     roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
