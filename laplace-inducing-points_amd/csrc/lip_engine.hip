@@ -138,6 +138,13 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       p.red1 = resolve(c, op.red1); p.red1_ps = op.red1.pstride;
       p.xhat2 = resolve(c, op.xhat2);
       if (!p.out || p.R <= 0 || p.N <= 0) { set_error("IGEMM: bad output"); return LIP_ERR_ARG; }
+      {   // the kernels index tensors with 32-bit arithmetic: refuse bindings that do not fit instead of wrapping
+        const long long lim = 1ll << 31;
+        bool fits = (long long)p.R * p.N < lim;
+        for (int s = 0; s < op.nseg; ++s)
+          fits = fits && (long long)op.n_img * p.seg[s].IH * p.seg[s].IW * p.seg[s].C < lim && (long long)p.seg[s].Ktot * p.N < lim;
+        if (!fits) { set_error("IGEMM: a tensor of this binding has 2^31 or more elements; bind fewer examples per engine (ExampleChunkedGGN)"); return LIP_ERR_ARG; }
+      }
       if (p.e1 && !p.xhat) { set_error("IGEMM: e1 without xhat"); return LIP_ERR_ARG; }
       if (p.red1 && !p.xhat2) { set_error("IGEMM: red1 without xhat2"); return LIP_ERR_ARG; }
       if (c.rows && (p.red0 || p.red1)) {
@@ -167,6 +174,10 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
         p.ksplit = op.n_img; p.seg_rows = p.OHW; p.seg_ys = p.y_ps; p.y_ps *= op.n_img;
       }
       if (!p.a || !p.g || !p.y || p.R <= 0 || p.N <= 0 || p.M <= 0) { set_error("WGRAD: bad operands"); return LIP_ERR_ARG; }
+      if ((long long)p.R * p.N >= (1ll << 31) || (long long)op.n_img * p.IH * p.IW * p.C >= (1ll << 31) || (long long)p.M * p.N >= (1ll << 31)) {
+        set_error("WGRAD: a tensor of this binding has 2^31 or more elements; bind fewer examples per engine (ExampleChunkedGGN)");
+        return LIP_ERR_ARG;
+      }
       if ((p.C & 3) == 0 && (((uintptr_t)p.a) & 15)) { set_error("WGRAD: activations not 16-byte aligned"); return LIP_ERR_ARG; }
       RUN_CHECK(launch_wgrad(p, c.P, c.st), "wgrad launch");
       return LIP_OK;
