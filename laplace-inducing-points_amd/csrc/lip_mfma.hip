@@ -1223,14 +1223,6 @@ static int tile_override() {
   return v;
 }
 
-hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
-  const bool small_m = p.R <= 64;
-  const bool big_m = p.R >= 4096 && tile_override() == 1;    // LIP_TILE=1: 256-row tiles (A/B: 15% slower on MI355X, r2)
-  if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);
-  if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 2>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st));
-  return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st));
-}
-
 static int cu_count() {
   static int n = 0;
   if (!n) {
@@ -1242,17 +1234,42 @@ static int cu_count() {
   return n;
 }
 
+hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
+  // Few probes (single-vector Krylov loops): with fewer 128-row blocks than CUs the launch time is ONE block's K loop,
+  // so take the tiles with the least work per wave (32x32 per wave, 64-row blocks) — at P = 1 the 128-channel layers
+  // of the CIFAR net run 25 blocks of 144 K-tiles otherwise (measured 177 us per launch).  A/B switch LIP_NOSMALLP.
+  static const bool nosmallp = getenv("LIP_NOSMALLP") != nullptr;
+  const long long blocks128 = (long long)((p.R + 127) / 128) * ((p.N + (p.N > 64 ? 127 : (p.N > 32 ? 63 : 31))) / (p.N > 64 ? 128 : (p.N > 32 ? 64 : 32))) * P;
+  if (!nosmallp && p.R > 64 && blocks128 < cu_count()) {
+    if (p.N > 32) return run_igemm<2, 2, 1, 1>(p, P, st);
+    return run_igemm<2, 1, 1, 1>(p, P, st);
+  }
+  const bool small_m = p.R <= 64;
+  const bool big_m = p.R >= 4096 && tile_override() == 1;    // LIP_TILE=1: 256-row tiles (A/B: 15% slower on MI355X, r2)
+  if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);
+  if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 2>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st));
+  return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st));
+}
+
+
 // Row split (float atomics into Y) of a weight-gradient launch with `blocks` blocks before splitting and `occ`
 // resident blocks per CU.  Blocks are long (R/16 K-tiles) and, at small probe counts, few: 640 blocks on 768 slots
 // leave a sixth of the chip idle, 1152 on 512 run a third round a quarter full.  Fill the chip when under-filled
 // and otherwise prefer a split that ends on a whole number of rounds, but only while a launch has few rounds (at
 // 256 probes the same rule measured +-0).  >= 64 K-tiles stay in every split.
-static int auto_ksplit(long long blocks, int occ, int R) {
+static int auto_ksplit(long long blocks, int occ, int R, int tile_elems, int mfma_per_wave_tile) {
   const double slots = (double)cu_count() * occ;
   const int maxks = R / (64 * BK) > 0 ? R / (64 * BK) : 1;
-  if ((double)blocks < slots) {                     // under-filled (few probes): down to 4 K-tiles per split
-    long long ks = (long long)((2.0 * slots + blocks - 1) / blocks);
-    const long long cap = R / 64 > 0 ? R / 64 : 1;
+  if ((double)blocks < slots) {
+    // under-filled (few probes): splitting shortens every block's K loop (~700 + 64 * MFMAs cycles per 16-row K-tile
+    // for a lone wave) but each split adds tile_elems float atomics per block, which the L2 retires at ~128 per clock
+    // chip-wide: minimise  ktiles * cycles_per_tile / ks  +  ks * blocks * tile_elems / 128  — e.g. ks = 22 rather
+    // than "fill the chip" (50) for the 1152 x 128 weight gradient at one probe (measured 50 -> 21 us).
+    const double ktiles = (double)R / BK, per_tile = 700.0 + 64.0 * mfma_per_wave_tile;
+    double ks_opt = sqrt(ktiles * per_tile / ((double)blocks * tile_elems / 128.0));
+    long long ks = (long long)(ks_opt + 0.5);
+    const long long fill = (long long)((2.0 * slots + blocks - 1) / blocks), cap = R / 64 > 0 ? R / 64 : 1;
+    if (ks > fill) ks = fill;
     if (ks > cap) ks = cap;
     if (ks > 1024) ks = 1024;
     return (int)(ks < 1 ? 1 : ks);
@@ -1273,7 +1290,7 @@ static hipError_t run_wgrad(const WgradP& p0, int P, hipStream_t st) {
   using T = Tile<WM, WN, TM, TN>;
   const long long tiles = (long long)((p0.M + T::BM - 1) / T::BM) * ((p0.N + T::BN - 1) / T::BN);
   WgradP p = p0;
-  if (p.ksplit <= 0) p.ksplit = auto_ksplit(tiles * P, TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4), p.R);
+  if (p.ksplit <= 0) p.ksplit = auto_ksplit(tiles * P, TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4), p.R, T::BM * T::BN, 8 * TM * TN);
   dim3 grid((unsigned)tiles, (unsigned)P, (unsigned)p.ksplit);
   static const bool force_generic = getenv("LIP_GENERIC") != nullptr;     // A/B switch
   if (!force_generic && (p.C & 3) == 0 && (((uintptr_t)p.a) & 15) == 0) {
