@@ -1240,7 +1240,8 @@ hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   // of the CIFAR net run 25 blocks of 144 K-tiles otherwise (measured 177 us per launch).  A/B switch LIP_NOSMALLP.
   static const bool nosmallp = getenv("LIP_NOSMALLP") != nullptr;
   const long long blocks128 = (long long)((p.R + 127) / 128) * ((p.N + (p.N > 64 ? 127 : (p.N > 32 ? 63 : 31))) / (p.N > 64 ? 128 : (p.N > 32 ? 64 : 32))) * P;
-  if (!nosmallp && p.R > 64 && blocks128 < cu_count()) {
+  static const int smallp_factor = getenv("LIP_SMALLP_FACTOR") ? atoi(getenv("LIP_SMALLP_FACTOR")) : 2;   // 1..4 measured: +-3 %
+  if (!nosmallp && p.R > 64 && blocks128 < (long long)smallp_factor * cu_count()) {
     if (p.N > 32) return run_igemm<2, 2, 1, 1>(p, P, st);
     return run_igemm<2, 1, 1, 1>(p, P, st);
   }
