@@ -44,32 +44,40 @@ def cpu_baseline(net, n, seconds_budget=12.0):
     D = sum(t.numel() for t in _leaves(st.params["params"]))
     v = torch.randn(D, generator=g)
 
-    def rate(factory, n_s):
+    def rate(factory, n_s, budget=seconds_budget):
         Z = torch.rand((n_s,) + tuple(net.input_shape_raw), generator=g)
         vp = factory(st, Z, "classifier", full_set_size=49000)
         vp(v)                                             # warm-up
         t0, reps = time.perf_counter(), 0
-        while reps < 1 or (time.perf_counter() - t0 < seconds_budget and reps < 5):
+        while reps < 1 or (time.perf_counter() - t0 < budget and reps < 5):
             vp(v)
             reps += 1
         dt = (time.perf_counter() - t0) / reps
         return 1.0 / (dt / n_s * n), reps                 # GGN-vp/s over n examples (linear in examples)
 
-    lit, reps_a = rate(vp_literal, min(n, 4))
-    bat, reps_b = rate(vp_batched, n)
-    cores = torch.get_num_threads()
-    bat8 = None
-    if cores > 8:                                         # also at 8 threads, comparable across hosts
-        torch.set_num_threads(8)
+    all_threads = torch.get_num_threads()
+    lit_nt = min(all_threads, 8)                          # the per-example loop is small-GEMM work: 8 threads beat 128
+    torch.set_num_threads(lit_nt)
+    try:
+        lit, reps_a = rate(vp_literal, min(n, 4), budget=seconds_budget / 2)
+    finally:
+        torch.set_num_threads(all_threads)
+    by_threads = {}
+    for nt in sorted({all_threads, min(all_threads, 32), min(all_threads, 16), min(all_threads, 8)}, reverse=True):
+        torch.set_num_threads(nt)                         # more threads is not faster here: report the best count
         try:
-            bat8, _ = rate(vp_batched, n)
+            by_threads[nt], reps_b = rate(vp_batched, n, budget=seconds_budget / 2)
         finally:
-            torch.set_num_threads(cores)
-    return dict(value=max(lit, bat), unit="GGN-vp/s", cores=cores, kind="port",
-                literal_per_example=lit, example_batched=bat, example_batched_at_8_threads=bat8,
-                sample=f"CPU restatement in PyTorch fp32 (not reference JAX): (a) literal per-example loop, {reps_a} x "
-                       f"(1 probe x {min(n, 4)} of {n} examples) extrapolated linearly; (b) example-batched, {reps_b} x "
-                       f"(1 probe x all {n} examples)")
+            torch.set_num_threads(all_threads)
+    best_nt = max(by_threads, key=by_threads.get)
+    bat = by_threads[best_nt]
+    return dict(value=max(lit, bat), unit="GGN-vp/s", cores=best_nt if bat >= lit else all_threads, kind="port",
+                literal_per_example=lit, example_batched=bat,
+                example_batched_by_threads={str(k): v for k, v in by_threads.items()}, host_threads=all_threads,
+                sample=f"CPU restatement in PyTorch fp32 (not reference JAX): (a) literal per-example loop at {lit_nt} "
+                       f"threads, {reps_a} x (1 probe x {min(n, 4)} of {n} examples) extrapolated linearly; (b) example-"
+                       f"batched, (1 probe x all {n} examples) repeated within {seconds_budget / 2:.0f} s per thread count "
+                       f"{sorted(by_threads)}; value = the best")
 
 
 def _leaves(tree):
@@ -279,6 +287,26 @@ def main():
                              "(1024 probes x 10k images over 8 GPUs = 160 such blocks x 16 probe chunks per GPU)")
         del e50, V50, Y50
 
+    # ---- the north star's Krylov route: D-space Lanczos on the matrix-free GGN + alpha I (36 matvecs, full re-orth.) ----
+    lanczos_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        from lip_amd.sample import sample_lanczos
+        st_l = state.to(device=dev, dtype=torch.float32)
+        Zl = Z.to(dev)
+        S_l, k_l = 64, 36
+        sample_lanczos(st_l, Zl, eng.D, alpha, 5, "classifier", num_samples=8, full_set_size=full, num_matvecs=4)   # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        SL = sample_lanczos(st_l, Zl, eng.D, alpha, 6, "classifier", num_samples=S_l, full_set_size=full, num_matvecs=k_l)
+        torch.cuda.synchronize()
+        t_l = time.perf_counter() - t1
+        lanczos_line = dict(value=S_l / t_l, unit="posterior samples/s", num_samples=S_l, num_matvecs=k_l, seconds=t_l,
+                            matvec_share=k_l * (S_l / value) / t_l, finite=bool(torch.isfinite(SL).all().item()),
+                            note="(GGN + alpha I)^(-1/2) eps by k-step Lanczos with CGS2 re-orthogonalisation on the "
+                                 "matrix-free product (block of 64 recurrences); matvec_share = k * block sweep time at the "
+                                 "headline rate / total: the rest is the HBM-bound Krylov kernels and the small eigh")
+        del SL
+
     krylov_line = None
     if args.samples > 0 and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -309,7 +337,7 @@ def main():
                                           "own block for the same probes (weak scaling), value = P * N / step time; "
                                           "example_probe_products_per_s = value * examples",
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:
