@@ -135,6 +135,17 @@ def test_cifar_resnet1m_full_size_properties():
     Gm = V @ Y.T                                       # (16, 16) = V G V^T
     assert torch.allclose(Gm, Gm.T, rtol=1e-3, atol=1e-3 * Gm.abs().max().item())
     assert torch.linalg.eigvalsh(0.5 * (Gm + Gm.T).double()).min() > -1e-3 * Gm.abs().max().item()
+    # the bench's block size takes other kernels than a 16-probe block (128-row tiles, probe-batched weight gradient,
+    # no row split): the first 16 rows of a 256-probe block must agree with the 16-probe block checked above
+    V256 = torch.cat([V, krylov.fill_rademacher(240, D, 4, "cuda")])
+    Y256 = vp(V256)
+    assert (Y256[:16] - Y).abs().max().item() <= 2e-5 * Y.abs().max().item()
+    assert torch.isfinite(Y256).all()
+    # per-example rows at full size: their sum over examples is the summed product
+    eng = vp.engine
+    U = torch.randn(4, eng.n, eng.K, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    rows = eng.vjp_rows(U, "l", 1.0)
+    assert (rows.sum(1) - eng.vjp(U, "l", 1.0)).abs().max().item() <= 2e-5 * rows.abs().max().item() * eng.n
 
 
 @pytest.mark.gpu
