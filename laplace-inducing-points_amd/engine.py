@@ -523,6 +523,8 @@ class LinearizedNet:
         if net is None:
             raise TypeError("the HIP engine needs state.net (a NetSpec layer program); an opaque apply_fn cannot "
                             "be differentiated by hand-written kernels, and there is no CPU fallback")
+        if Z.shape[0] == 0:
+            raise ValueError("empty data block: the engine needs at least one example (an empty sum is the zero operator)")
         self.lib = nv.load()
         if not torch.cuda.is_available():
             raise nv.NativeError("no GPU: the product path has no CPU fallback")

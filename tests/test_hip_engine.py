@@ -167,6 +167,8 @@ def test_edge_sizes_single_example_single_probe_and_empty_block():
     assert rows.shape == (1, 1, eng.D) and _rel(rows[:, 0], eng.vjp(torch.ones(1, 1, eng.K), "l", 1.0).double().cpu()) <= 1e-5
     with pytest.raises((nv.NativeError, ValueError, RuntimeError)):
         eng.ggn_vp(torch.zeros(0, eng.D), 1.0, 0.0)
+    with pytest.raises(ValueError):
+        LinearizedNet(st, Z[:0], "classifier")
 
 
 def test_missing_netspec_fails_loudly():

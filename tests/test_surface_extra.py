@@ -205,3 +205,24 @@ def test_resnet50_real_architecture_properties():
     ref = og.compute_ggn_vp_batched(st64, Z, "classifier", full_set_size=10000)(cpu64(V[0]))
     err = (cpu64(Y[0]) - ref).abs().max() / ref.abs().max()
     assert err < 5e-4, err
+
+
+@pytest.mark.gpu
+def test_predict_lla_marginals_equal_dense(classification_2d_data, classifier_state, sine_data, toyregressor_state):
+    """Closed-form per-point predictive (factor algebra + per-example Jacobian rows) == predict_lla_dense
+    (reference src/lla.py:51-82) on the toy problems where the dense D x D route is feasible."""
+    import src.lla as hl
+    X, y = classification_2d_data
+    st = classifier_state.to(device="cuda", dtype=torch.float32)
+    Z, Xn = X[:12].cuda().float(), X[12:19].cuda().float()
+    a = hl.predict_lla_dense(st, Xn, Z, "classifier", alpha=0.5, full_set_size=200)
+    b = hl.predict_lla_marginals(st, Xn, Z, "classifier", alpha=0.5, full_set_size=200, batch=4)
+    assert torch.allclose(cpu64(a.mean()), cpu64(b.mean()), atol=1e-5)
+    assert (cpu64(a.covariance()) - cpu64(b.covariance())).abs().max() <= 2e-4 * cpu64(a.covariance()).abs().max()
+    ref = olla.predict_lla_dense(classifier_state, X[12:19], X[:12], "classifier", 0.5, full_set_size=200)
+    assert (cpu64(b.covariance()) - ref.covariance()).abs().max() <= 2e-4 * ref.covariance().abs().max()
+    Xs, ys = sine_data
+    sr = toyregressor_state.to(device="cuda", dtype=torch.float32)
+    a = hl.predict_lla_dense(sr, Xs[10:15].cuda().float(), Xs[:10].cuda().float(), "regressor", alpha=0.5)
+    b = hl.predict_lla_marginals(sr, Xs[10:15].cuda().float(), Xs[:10].cuda().float(), "regressor", alpha=0.5)
+    assert (cpu64(a.covariance()) - cpu64(b.covariance())).abs().max() <= 2e-4 * cpu64(a.covariance()).abs().max()
