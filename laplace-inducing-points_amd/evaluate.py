@@ -62,7 +62,13 @@ def roc_auc(labels: torch.Tensor, scores: torch.Tensor) -> float:
 def batch_nll(state, x, y, Z, *, alpha, full_set_size, model_type, num_mc_samples, rng, scalable=True,
               return_mean=False):
     """``:98-154``: (NLL of the MC-averaged predictive, accuracy[, mean probabilities])."""
-    if scalable:
+    if scalable == "marginals":
+        # closed-form per-point predictive (lla.predict_lla_marginals): the metrics below only use per-point marginals,
+        # so the S draws can be taken in the K-dimensional output space instead of through S tangent sweeps
+        from .lla import predict_lla_marginals
+        dist = predict_lla_marginals(state, x, Z, model_type=model_type, alpha=alpha, full_set_size=full_set_size)
+        logit_samples = dist.sample(sample_shape=(num_mc_samples,), seed=rng).float()
+    elif scalable:
         logit_samples = predict_lla_scalable(state, x, Z, model_type=model_type, alpha=alpha,
                                              full_set_size=full_set_size, num_samples=num_mc_samples, key=rng)
     else:

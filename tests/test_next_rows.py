@@ -85,6 +85,8 @@ def test_eval_dataset_on_blobs(classification_2d_data, classifier_state):
     assert math.isfinite(nll) and 0.0 <= acc <= 1.0 and 0.0 <= bri <= 2.0 and 0.0 <= cal <= 1.0
     nll_d, acc_d = ev.eval_dataset(st, test, Z, 0.5, 200, "classifier", 400, rng=7, scalable=False)
     assert abs(nll - nll_d) < 0.05 and abs(acc - acc_d) < 0.05
+    nll_m, acc_m = ev.eval_dataset(st, test, Z, 0.5, 200, "classifier", 400, rng=7, scalable="marginals")
+    assert abs(nll_m - nll_d) < 0.02 and abs(acc_m - acc_d) < 0.02       # same per-point predictive, K-dim draws
     ood = [(torch.randn(50, 2).cuda() * 6.0, torch.zeros(50))]
     au = ev.auroc_ood(st, probs, ood, Z, 0.5, 200, "classifier", 200, rng=11)
     assert 0.0 <= au <= 1.0
