@@ -307,6 +307,27 @@ def main():
                                  "headline rate / total: the rest is the HBM-bound Krylov kernels and the small eigh")
         del SL
 
+    # ---- one evaluation batch (scale_experiments/evaluate.py:98-154 times its passes): MC predictive of 256 test images ----
+    eval_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        from lip_amd.lla import predict_lla_scalable
+        st_e = state.to(device=dev, dtype=torch.float32)
+        Ze = Z.to(dev)
+        Xw = torch.rand(256, 32, 32, 3, generator=torch.Generator().manual_seed(41)).to(dev)
+        Xe = torch.rand(256, 32, 32, 3, generator=torch.Generator().manual_seed(42)).to(dev)
+        predict_lla_scalable(st_e, Xw, Ze, "classifier", alpha, key=3, full_set_size=full, num_samples=args.samples)   # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        LS = predict_lla_scalable(st_e, Xe, Ze, "classifier", alpha, key=4, full_set_size=full, num_samples=args.samples)
+        torch.cuda.synchronize()
+        t_e = time.perf_counter() - t1
+        eval_line = dict(value=256 / t_e, unit="test images/s", batch=256, mc_samples=args.samples, seconds=t_e,
+                         tflops=4 * net.macs_per_example() * 256 * args.samples / t_e / 1e12,
+                         note="predict_lla_scalable (src/lla.py:133-156): the S draws (cached sampler parts) pushed through "
+                              "one tangent-forward block on an engine bound to the test batch; FLOPs = 4 MACs per "
+                              "(image, draw)", finite=bool(torch.isfinite(LS).all().item()))
+        del LS, Xw, Xe
+
     krylov_line = None
     if args.samples > 0 and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -337,7 +358,7 @@ def main():
                                           "own block for the same probes (weak scaling), value = P * N / step time; "
                                           "example_probe_products_per_s = value * examples",
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:
