@@ -89,3 +89,24 @@ def gather_rows(U_local: torch.Tensor, group=None) -> torch.Tensor:
     parts = [torch.empty_like(U_local) for _ in range(dist.get_world_size(group))]
     dist.all_gather(parts, U_local.contiguous(), group=group)
     return torch.cat(parts, dim=1)
+
+
+def sharded_hutchinson(op: Callable[[torch.Tensor], torch.Tensor], probes: torch.Tensor, group=None) -> torch.Tensor:
+    """Hutchinson estimate mean_p eps_p^T X eps_p (``src/stochtrace.py:22-34``) with the PROBES sharded over ranks:
+    every rank holds the whole operator (``op`` maps a (p, D) block to a (p, D) block — e.g. a ``ShardedDataSum`` when
+    the data is sharded as well, or a rank-local engine over all the data), takes its contiguous slice of the ``(P, D)``
+    probe block, and the partial sums of the quadratic forms are combined by one scalar all-reduce."""
+    P = probes.shape[0]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = shard_bounds(P, world, rank)
+    if hi > lo:
+        mine = probes[lo:hi]
+        part = (mine * op(mine)).sum(dtype=torch.float64)
+    else:
+        part = torch.zeros((), dtype=torch.float64, device=probes.device)
+    if world > 1:
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return part / P

@@ -15,7 +15,7 @@ def _worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import lip_amd  # noqa: F401
-    from lip_amd.dist import ShardedDataSum, gather_rows, shard_bounds
+    from lip_amd.dist import ShardedDataSum, gather_rows, shard_bounds, sharded_hutchinson
     from lip_amd.toymodels import SimpleClassifier, create_state
     from oracle.ggn import compute_ggn_vp, compute_W_vps
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -54,7 +54,13 @@ def _worker(rank, world, port, ret):
     _, WT_full = compute_W_vps(st, Z8, "classifier")
     U = gather_rows(WT_loc(V[0])[None])[0]
     err2 = (U - WT_full(V[0])).abs().max().item()
-    ret[rank] = (err, err2)
+    # probes sharded over ranks: every rank applies the full operator to its slice, one scalar all-reduce
+    probes = torch.sign(torch.randn(5, 81, dtype=torch.float64, generator=g))
+    full_op = lambda B: torch.stack([vp_full(v) for v in B])
+    tr = sharded_hutchinson(full_op, probes)
+    tr_ref = (probes * full_op(probes)).sum() / 5
+    err3 = abs(float(tr) - float(tr_ref))
+    ret[rank] = (err, err2 + err3)
     dist.destroy_process_group()
 
 
