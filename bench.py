@@ -183,9 +183,11 @@ def main():
                                "2*MACs of its conv, WGRAD 2*R*N*M (= 8*MACs_fwd per example-probe minus the input "
                                "layer's two absent terms, SURVEY 8d)")
 
-    # ---- posterior samples/s (single-rank figure; reference algorithm src/sample.py:55-156) -----------
+    # ---- posterior samples/s (reference algorithm src/sample.py:55-156).  N > 1: the inducing set is small, every
+    # rank holds it and draws its own args.samples with its own seed (replicas, no collective); whole-job rate =
+    # N * samples / slowest rank -----------
     samples_line = None
-    if args.samples > 0 and rank == 0 and world == 1:
+    if args.samples > 0:
         from lip_amd.sample import sample
         st_dev = state.to(device=dev, dtype=torch.float32)
         Zd = Z.to(dev)
@@ -200,17 +202,21 @@ def main():
         from lip_amd import sample as _smod
         _smod._PARTS_CACHE.clear()
         clear_engine_cache()
-        torch.cuda.synchronize()
+        barrier()
         t1 = time.perf_counter()
-        S = sample(st_dev, Zd, eng.D, alpha, 1392, "classifier", num_samples=args.samples, full_set_size=full)
+        S = sample(st_dev, Zd, eng.D, alpha, 1392 + rank, "classifier", num_samples=args.samples, full_set_size=full)
         torch.cuda.synchronize()
         ts = time.perf_counter() - t1
         t1 = time.perf_counter()
-        S = sample(st_dev, Zd, eng.D, alpha, 1393, "classifier", num_samples=2000, full_set_size=full)
+        S = sample(st_dev, Zd, eng.D, alpha, 2393 + rank, "classifier", num_samples=2000, full_set_size=full)
         torch.cuda.synchronize()
         ts2 = time.perf_counter() - t1
-        samples_line = dict(value=args.samples / ts, unit="posterior samples/s", num_samples=args.samples,
-                            seconds=ts, at_2000_samples_same_binding=2000 / ts2,
+        if world > 1:
+            tt = torch.tensor([ts, ts2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts, ts2 = float(tt[0].item()), float(tt[1].item())
+        samples_line = dict(value=world * args.samples / ts, unit="posterior samples/s", num_samples=world * args.samples,
+                            seconds=ts, at_2000_samples_same_binding=world * 2000 / ts2, ranks=world,
                             includes="fresh (state, Z) binding: engine build + primal pass + factor rows (one per-example "
                                      "backward sweep of K probes) + float64 Gram + exact small-space f(A), then W^T / W "
                                      "as GEMMs; the second figure reuses the binding (2000 draws)",
