@@ -129,6 +129,7 @@ def main():
     V = krylov.fill_rademacher(P, eng.D, 1234, dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
