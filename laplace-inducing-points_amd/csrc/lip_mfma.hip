@@ -932,8 +932,22 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
   const int N = prm.N, M = prm.M;
   const int NC = PB ? prm.P * N : N;           // GEMM columns of this launch
   const int tiles_n = (NC + BN - 1) / BN;
-  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
-  const int p = PB ? 0 : blockIdx.y;
+  // Workgroups go round-robin over the 8 XCDs: remap the (tile, probe) index so that every XCD works through a
+  // CONTIGUOUS run of it — the row tiles of one probe (which all stream the same cotangent rows) and the column tiles
+  // over one activation slab then share an L2 instead of fetching the operand once per XCD.
+  int bx = blockIdx.x, by = PB ? 0 : (int)blockIdx.y;
+  {
+    const int gx = (int)gridDim.x, tot = gx * (PB ? 1 : (int)gridDim.y), g8 = tot & ~7;
+    const int lin = bx + gx * by;
+    if (lin < g8) {
+      const int w = (lin & 7) * (g8 >> 3) + (lin >> 3);
+      by = w / gx; bx = w - by * gx;
+    }
+  }
+  // PB: row tile fastest, so the (three) row tiles of one column tile — same cotangent columns — are neighbours
+  const int tiles_m = (int)gridDim.x / tiles_n;
+  const int tile_n = PB ? bx / tiles_m : bx % tiles_n, tile_m = PB ? bx - tile_n * tiles_m : bx / tiles_n;
+  const int p = by;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int rows_per = (prm.R + prm.ksplit - 1) / prm.ksplit;
