@@ -508,10 +508,24 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   // the halo rows two neighbouring tiles both gather come out of one L2.  Measured on the 32-column tile (400 tiles per
   // probe): HBM reads 6.62 -> 5.18 GB per launch, time -1 %.  Not for the parity-class grid (its order is by class:
   // 4.72 -> 6.5 GB and +50 % time when remapped).
-  int bid = blockIdx.x;
+  int bid = blockIdx.x, byp = blockIdx.y;
   if (!PAR) {
-    const int g8 = (int)gridDim.x & ~7;
-    if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+    const int gx = (int)gridDim.x;
+    if (gx >= 64) {
+      // many row tiles per probe (large feature maps): an XCD keeps the SAME tile range for every probe, so the
+      // primal operands of those rows (activations, x-hat, act') stay in its L2 across the probes
+      const int g8 = gx & ~7;
+      if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+    } else {
+      // few row tiles per probe (small feature maps, large per-probe weight slices): an XCD works through whole
+      // probes, so a probe's weight slice is fetched into one L2 only (128-column tile: 3.3 -> 2.4 GB per launch;
+      // on the 32- and 64-column tiles this order was measured worse: 6.9 -> 8.4 and 3.7 -> 4.5 GB)
+      const int g8 = (gx * (int)gridDim.y) & ~7, lin = bid + gx * byp;
+      if (lin < g8) {
+        const int w = (lin & 7) * (g8 >> 3) + (lin >> 3);
+        byp = w / gx; bid = w - byp * gx;
+      }
+    }
   }
   const int tile_n = bid % tiles_n;
   int tile_m = bid / tiles_n, ph = 0, pw = 0;
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
     const int tpc = (prm.Rc + BM - 1) / BM, cls = tile_m / tpc;
     tile_m -= cls * tpc; ph = cls >> 1; pw = cls & 1;
   }
-  const int p = blockIdx.y;
+  const int p = byp;
   const int r0 = tile_m * BM, n0 = tile_n * BN;
 
   for (int i = tid; i < 2 * BN; i += NT) redbuf[i] = 0.f;
