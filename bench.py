@@ -4,15 +4,24 @@
 Workload (BASELINE.json configs[3]): CIFAR-CNN `ResNet1M` (D = 1 084 586,
 162 366 720 MACs/example), synthetic inputs X ~ U[0,1]^(n x 32 x 32 x 3) with n = 50 inducing points
 per GPU, seeded random-init weights + BN statistics, P = 256 Rademacher probes, alpha = 0.005,
-full_set_size = 49 000.  One *step* = one block matvec  V (P, D) -> (GGN + alpha I) V  over the rank's
-data slice, followed (N > 1) by ONE all-reduce of the (P, D) block — the data sum shards across ranks
-(weak scaling: every rank holds its own 50-example slice).  `value` = P * N * steps / time, i.e.
-GGN-vector products per second counted per 50-example data shard, inputs resident in HBM.
+full_set_size = 49 000.  One *step* = one block matvec  V (P, D) -> (GGN + alpha I) V  over the WHOLE data set
+of 50 * N examples: every rank sweeps its own 50-example slice for the same P probes, then ONE all-reduce of the
+(P, D) block adds the partial sums (the data sum shards across ranks; weak scaling: per-GPU work is fixed).
+`value` = P * steps / time — GGN-vector products per second over the whole 50 * N-example set (one
+GGN-vp = one product over ALL examples of the config), inputs resident in HBM; the per-shard and the
+per-(example x probe) rates are secondary fields.
+
+`--gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (one child process per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything touches the GPU; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks already exist and the flag is
+only checked against WORLD_SIZE.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -88,6 +97,43 @@ def _leaves(tree):
         yield tree
 
 
+def spawn_ranks(n_ranks: int, argv) -> int:
+    """`bench.py --gpus N` outside a launcher: start N copies of this script, one rank per GPU, and wait.  Nothing in
+    this (parent) process has initialised HIP — `torch.cuda.device_count()` does not on this image — and the children
+    are ordinary child processes (no exec of a GPU-initialised process).  A rank that fails takes the others down
+    and its exit code becomes ours.  Fewer GPUs than ranks is refused unless LIP_DIST_BACKEND=gloo asks for the
+    rehearsal of the N-rank path on the cards that exist (ranks share GPUs round-robin, collectives over gloo)."""
+    ndev = torch.cuda.device_count()
+    rehearsal = os.environ.get("LIP_DIST_BACKEND", "nccl") != "nccl"
+    if ndev < n_ranks and not rehearsal:
+        print(f"bench.py: --gpus {n_ranks} but only {ndev} GPU(s) visible; refusing to run fewer ranks than asked "
+              "(LIP_DIST_BACKEND=gloo rehearses the N-rank path on the GPUs present)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:               # exact PIDs of our own children, never a pattern
+                    other.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +146,12 @@ def main():
     ap.add_argument("--no-resnet50", action="store_true", help="skip the full-resolution ResNet-50 slice (configs[4])")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = max(1, torch.cuda.device_count())
@@ -147,7 +198,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
-    value = P * world * args.steps / dt
+    value = P * args.steps / dt                    # products over the WHOLE n_total-example set per second
+    per_shard = value * world                      # products counted per 50-example shard (round-1 unit)
 
     # ---- live per-kernel figure: HIP events on the launch stream, instrumented extra steps -------------
     eng.profile(True)
@@ -308,7 +360,7 @@ def main():
         torch.cuda.synchronize()
         t_l = time.perf_counter() - t1
         lanczos_line = dict(value=S_l / t_l, unit="posterior samples/s", num_samples=S_l, num_matvecs=k_l, seconds=t_l,
-                            matvec_share=k_l * (S_l / value) / t_l, finite=bool(torch.isfinite(SL).all().item()),
+                            matvec_share=k_l * (S_l / per_shard) / t_l, finite=bool(torch.isfinite(SL).all().item()),
                             note="(GGN + alpha I)^(-1/2) eps by k-step Lanczos with CGS2 re-orthogonalisation on the "
                                  "matrix-free product (block of 64 recurrences); matvec_share = k * block sweep time at the "
                                  "headline rate / total: the rest is the HBM-bound Krylov kernels and the small eigh")
@@ -354,16 +406,21 @@ def main():
         cpu = cpu_baseline(net, n)
 
     if rank == 0:
-        line = dict(metric="GGN-vector products/sec", value=value, example_probe_products_per_s=value * n, unit="GGN-vp/s", n_gpus=world, steps=args.steps,
+        line = dict(metric="GGN-vector products/sec", value=value, example_probe_products_per_s=value * n_total,
+                    per_shard_products_per_s=per_shard, unit="GGN-vp/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload="CIFAR-CNN ResNet1M GGN-vp (BASELINE configs[3]): D=1084586, "
                                          f"n={n} examples/GPU, P={P} Rademacher probes/block, alpha=0.005, "
                                          "full_set_size=49000; data sum sharded over ranks, one all-reduce per matvec",
-                                examples_per_gpu=n, probes=P, D=eng.D, probe_chunk=eng.chunk,
-                                unit_note=f"one GGN-vp = one product over a {n}-example data block; N ranks each sweep their "
-                                          "own block for the same probes (weak scaling), value = P * N / step time; "
-                                          "example_probe_products_per_s = value * examples",
+                                examples_per_gpu=n, examples_total=n_total, probes=P, D=eng.D, probe_chunk=eng.chunk,
+                                backend=(os.environ.get("LIP_DIST_BACKEND", "nccl") if world > 1 else None),
+                                physical_gpus=ndev,
+                                unit_note=f"one GGN-vp = one product over the WHOLE data set of {n_total} examples "
+                                          f"({n} per GPU, weak scaling: the set grows with N); value = P / step time; "
+                                          "per_shard_products_per_s = value * N counts a product per 50-example shard; "
+                                          "example_probe_products_per_s = value * examples_total is the figure that "
+                                          "grows with N under weak scaling",
                                 parallelism=f"data-shard x{world}"),
                     roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))

@@ -83,19 +83,40 @@ def sharded_ggn_vp(state, Z_local, model_type, alpha, n_total: int, full_set_siz
 
 
 def gather_rows(U_local: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather of the W^T slices (P, M_local, K) along the example axis (equal slice sizes)."""
+    """All-gather of the W^T slices (P, M_local, K) along the example axis.  ``shard_bounds`` hands out ragged
+    slices (sizes differ by at most one), so the slice lengths are gathered first and every slice is padded to
+    the longest one for the collective; the padding is cut away again before the concatenation."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return U_local
-    parts = [torch.empty_like(U_local) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(parts, U_local.contiguous(), group=group)
-    return torch.cat(parts, dim=1)
+    world = dist.get_world_size(group)
+    mine = torch.tensor([U_local.shape[1]], device=U_local.device, dtype=torch.int64)
+    sizes = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m_max = max(sizes)
+    pad = U_local.contiguous()
+    if pad.shape[1] < m_max:
+        fill = torch.zeros((pad.shape[0], m_max - pad.shape[1]) + tuple(pad.shape[2:]), device=pad.device, dtype=pad.dtype)
+        pad = torch.cat([pad, fill], dim=1)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:, :m] for p, m in zip(parts, sizes)], dim=1)
 
 
 def sharded_hutchinson(op: Callable[[torch.Tensor], torch.Tensor], probes: torch.Tensor, group=None) -> torch.Tensor:
     """Hutchinson estimate mean_p eps_p^T X eps_p (``src/stochtrace.py:22-34``) with the PROBES sharded over ranks:
-    every rank holds the whole operator (``op`` maps a (p, D) block to a (p, D) block — e.g. a ``ShardedDataSum`` when
-    the data is sharded as well, or a rank-local engine over all the data), takes its contiguous slice of the ``(P, D)``
-    probe block, and the partial sums of the quadratic forms are combined by one scalar all-reduce."""
+    every rank holds the WHOLE operator, takes its contiguous slice of the ``(P, D)`` probe block, and the partial
+    sums of the quadratic forms are combined by one scalar all-reduce.
+
+    ``op`` must be rank-local (a (p, D) -> (p, D) map that issues no collective on ``group``): the ranks call it on
+    DIFFERENT probe slices — of different lengths when P % world != 0, and not at all when a slice is empty — so a
+    :class:`ShardedDataSum` over the same group would add products of different probes, or deadlock.  Such an
+    operator is refused; to shard data and probes together give the data sum its own (disjoint) process group."""
+    if isinstance(op, ShardedDataSum) and op._world() > 1:
+        world_ranks = lambda g: sorted(dist.get_process_group_ranks(g if g is not None else dist.group.WORLD))
+        if set(world_ranks(op.group)) & set(world_ranks(group)) != {dist.get_rank()}:
+            raise ValueError("sharded_hutchinson: `op` all-reduces over ranks that also shard the probes; pass a "
+                             "rank-local operator, or a ShardedDataSum whose group is disjoint from the probe group")
     P = probes.shape[0]
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world, rank = dist.get_world_size(group), dist.get_rank(group)

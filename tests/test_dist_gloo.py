@@ -47,19 +47,32 @@ def _worker(rank, world, port, ret):
     vp_full = compute_ggn_vp(st, Z, "classifier", full_set_size=N)
     ref = torch.stack([vp_full(v) + alpha * v for v in V])
     err = (Y - ref).abs().max().item()
-    # W^T slices gather to the full (M, K) block when the slices are equal-sized
-    Z8 = torch.randn(8, 2, dtype=torch.float64, generator=g)
-    lo8, hi8 = shard_bounds(8, world, rank)
-    _, WT_loc = compute_W_vps(st, Z8[lo8:hi8], "classifier")
-    _, WT_full = compute_W_vps(st, Z8, "classifier")
-    U = gather_rows(WT_loc(V[0])[None])[0]
-    err2 = (U - WT_full(V[0])).abs().max().item()
+    # W^T slices gather to the full (M, K) block: equal slices (8 = 4 + 4) and the ragged ones shard_bounds
+    # hands out (7 = 4 + 3)
+    err2 = 0.0
+    for m in (8, 7):
+        Zm = torch.randn(m, 2, dtype=torch.float64, generator=g)
+        lom, him = shard_bounds(m, world, rank)
+        _, WT_loc = compute_W_vps(st, Zm[lom:him], "classifier")
+        _, WT_full = compute_W_vps(st, Zm, "classifier")
+        U = gather_rows(WT_loc(V[0])[None])[0]
+        assert tuple(U.shape) == (m, 3)
+        err2 += (U - WT_full(V[0])).abs().max().item()
     # probes sharded over ranks: every rank applies the full operator to its slice, one scalar all-reduce
     probes = torch.sign(torch.randn(5, 81, dtype=torch.float64, generator=g))
     full_op = lambda B: torch.stack([vp_full(v) for v in B])
     tr = sharded_hutchinson(full_op, probes)
     tr_ref = (probes * full_op(probes)).sum() / 5
     err3 = abs(float(tr) - float(tr_ref))
+    # a single probe: rank 1's slice is empty — it must still reach the scalar all-reduce (no deadlock)
+    tr1 = sharded_hutchinson(full_op, probes[:1])
+    err3 += abs(float(tr1) - float((probes[:1] * full_op(probes[:1])).sum()))
+    # an operator that all-reduces over the SAME ranks would mix different probes: refused
+    try:
+        sharded_hutchinson(op, probes)
+        err3 += 1.0
+    except ValueError:
+        pass
     ret[rank] = (err, err2 + err3)
     dist.destroy_process_group()
 
