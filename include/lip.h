@@ -178,6 +178,18 @@ int lip_cg_update(float* x, float* r, const float* p, const float* Ap, const flo
 /* p = r + (rr_new/rr_old) p                                                              */
 int lip_cg_direction(float* p, const float* r, const float* rr_new, const float* rr_old, const int32_t* active,
                      int32_t P, int64_t N, void* stream);
+/* C (m, n) float64, overwritten = A B^T with A (m, K), B (n, K) float32 rows (row strides lda / ldb >= K, 4-byte
+ * alignment suffices) accumulated in float64: the tall-skinny inner products whose float32 accumulation is too coarse —
+ * the sampler's stiff-direction coefficients (src/sample.py:130-139 at cond 3e9), the Gram of Hutch++'s tall-skinny
+ * orthonormalisation and its projections G Q^T (src/stochtrace.py:124-131).                              */
+int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64_t ldb, int32_t n, int64_t K, double* C,
+                   void* stream);
+/* Out[i] = zscale * Z[i] + sum_j Cm[i][j] Y[j],  i < r: r combinations of the s rows of Y (s, N) in one streaming pass
+ * per 12 output rows; Cm (r, s) float64 row-major on the device, Z (r, N) optional (NULL: no addend).  Replaces
+ * jnp.linalg.qr's Q of src/stochtrace.py:128 (as L^-1 Y after a Gram factorisation) and the deflation
+ * G - (G Q) Q^T of :131.  Out must not alias Y or Z.                                                      */
+int lip_rows_combine(const double* Cm, const float* Y, int64_t ldy, int32_t s, const float* Z, int64_t ldz, float zscale,
+                     float* Out, int64_t ldo, int32_t r, int64_t N, void* stream);
 /* counter-based Rademacher (+-1) / standard-normal fill of a (P, N) block               */
 int lip_fill_rademacher(float* X, int32_t P, int64_t N, uint64_t seed, void* stream);
 int lip_fill_normal(float* X, int32_t P, int64_t N, uint64_t seed, void* stream);

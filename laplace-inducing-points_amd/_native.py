@@ -76,6 +76,9 @@ SIGNATURES = {
     "lip_scale_store": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _V]),
     "lip_cg_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int64, _V]),
     "lip_cg_direction": (C.c_int, [_V, _V, _V, _V, _V, C.c_int32, C.c_int64, _V]),
+    "lip_dot_nt_f64": (C.c_int, [_V, C.c_int64, C.c_int32, _V, C.c_int64, C.c_int32, C.c_int64, _V, _V]),
+    "lip_rows_combine": (C.c_int, [_V, _V, C.c_int64, C.c_int32, _V, C.c_int64, C.c_float, _V, C.c_int64, C.c_int32,
+                                   C.c_int64, _V]),
     "lip_fill_rademacher": (C.c_int, [_V, C.c_int32, C.c_int64, C.c_uint64, _V]),
     "lip_fill_normal": (C.c_int, [_V, C.c_int32, C.c_int64, C.c_uint64, _V]),
 }
@@ -95,7 +98,9 @@ def load() -> C.CDLL:
     # torch bundles its own HIP runtime (libamdhip64 of its ROCm build).  It must be the one resident in
     # the process before liblip_hip.so is opened, otherwise the library binds the system runtime and the
     # two disagree about devices ("no ROCm-capable device is detected" at the first launch).
-    import torch  # noqa: F401
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()      # enforce "torch first" (the cause of an early `no ROCm-capable device` smoke failure)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

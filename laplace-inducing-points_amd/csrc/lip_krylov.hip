@@ -243,6 +243,135 @@ __global__ __launch_bounds__(KT) void cg_direction_kernel(float* Pd, const float
             [&](long long o) { pd[o] = r[o] + b * pd[o]; });
 }
 
+
+// ---- C = A B^T with float64 accumulation: A (m, K), B (n, K) float32, rows K-contiguous (row strides lda / ldb, any
+// 4-byte alignment), C (m, n) float64.  The tall-skinny inner products of the posterior engine: the coefficients
+// <q_k, v> of the sampler's stiff directions (cond(A) ~ 3e9: a float32-accumulated dot of length 1e6 is two decades too
+// coarse there), the Gram Y Y^T of CholeskyQR2 / Hutch++ (src/stochtrace.py:124-133), the projections G Q^T.
+// Every f32 x f32 product is exact in float64, so the result carries one rounding per addition at 1e-16.
+// Block = 32 x 32 output tile x one K-range; K-chunks of 64 are staged k-major in LDS (transposed on the way in), each
+// of the four waves takes 16 of the 64 k's with a 4 x 4 micro-tile per lane (two ds_read_b128 per 16 v_fma_f64), the
+// waves' partial tiles meet in LDS and leave as ONE float64 atomic per output element and block.
+constexpr int DT_B = 32, DT_KC = 64, DT_LD = DT_B + 4;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ __launch_bounds__(256) void dot_nt_f64_kernel(const float* __restrict__ A, long long lda, int m,
+                                                         const float* __restrict__ B, long long ldb, int n, long long K,
+                                                         long long kper, double* __restrict__ C) {
+  __shared__ __attribute__((aligned(16))) float As[DT_KC * DT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[DT_KC * DT_LD];
+  __shared__ double red[3 * DT_B * DT_B];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane >> 3, lj = lane & 7;
+  const int tiles_n = (n + DT_B - 1) / DT_B;
+  const int m0 = (blockIdx.x / tiles_n) * DT_B, n0 = (blockIdx.x % tiles_n) * DT_B;
+  const long long kb = (long long)blockIdx.y * kper, ke = (kb + kper < K) ? kb + kper : K;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  // loader: quad q = tid + j * 256 -> (row = q >> 4, k = 4 * (q & 15))
+  auto stage = [&](const float* __restrict__ X, long long ldx, int rows, int r0, float* __restrict__ Xs, long long k0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = tid + j * 256, row = q >> 4, kq = 4 * (q & 15);
+      const long long k = k0 + kq;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      if (r0 + row < rows && k < ke) {
+        const float* src = X + (long long)(r0 + row) * ldx + k;
+        if (k + 3 < ke) { const f4u v = *reinterpret_cast<const f4u*>(src); v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3]; }
+        else { v0 = src[0]; if (k + 1 < ke) v1 = src[1]; if (k + 2 < ke) v2 = src[2]; }
+      }
+      Xs[(kq + 0) * DT_LD + row] = v0; Xs[(kq + 1) * DT_LD + row] = v1;
+      Xs[(kq + 2) * DT_LD + row] = v2; Xs[(kq + 3) * DT_LD + row] = v3;
+    }
+  };
+  for (long long k0 = kb; k0 < ke; k0 += DT_KC) {
+    stage(A, lda, m, m0, As, k0);
+    stage(B, ldb, n, n0, Bs, k0);
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < DT_KC / 4; ++kk) {
+      const int k = wave * (DT_KC / 4) + kk;
+      const float4 a = *reinterpret_cast<const float4*>(&As[k * DT_LD + 4 * li]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[k * DT_LD + 4 * lj]);
+      const double ad[4] = {(double)a.x, (double)a.y, (double)a.z, (double)a.w};
+      const double bd[4] = {(double)b.x, (double)b.y, (double)b.z, (double)b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(ad[i], bd[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wave - 1) * DT_B * DT_B + (4 * li + i) * DT_B + 4 * lj + j] = acc[i][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = (4 * li + i) * DT_B + 4 * lj + j;
+        const double v = acc[i][j] + red[e] + red[DT_B * DT_B + e] + red[2 * DT_B * DT_B + e];
+        const int r = m0 + 4 * li + i, c = n0 + 4 * lj + j;
+        if (r < m && c < n) unsafeAtomicAdd(C + (long long)r * n + c, v);
+      }
+  }
+}
+
+// ---- Out[i] = zscale * Z[i] + sum_j Cm[i][j] Y[j]: r combinations of the s rows of Y (s, N), streamed once per tile of
+// RT output rows — the "triangular solve" of CholeskyQR2 (Q = L^-1 Y), the Hutch++ deflation G - (G Q^T) Q
+// (src/stochtrace.py:131) and the change of basis of a factor.  Coefficients arrive in float64 and are rounded once.
+template <int RT>
+__global__ __launch_bounds__(256) void rows_combine_kernel(const double* __restrict__ Cm, const float* __restrict__ Y,
+                                                           long long ldy, int s, const float* __restrict__ Z, long long ldz,
+                                                           float zscale, float* __restrict__ Out, long long ldo, int r,
+                                                           long long N) {
+  extern __shared__ float cs[];   // [RT][s]
+  const int r0 = blockIdx.x * RT;
+  for (int e = threadIdx.x; e < RT * s; e += 256) {
+    const int t = e / s, j = e - t * s;
+    cs[e] = (r0 + t < r) ? (float)Cm[(long long)(r0 + t) * s + j] : 0.f;
+  }
+  __syncthreads();
+  const long long col = 4ll * ((long long)blockIdx.y * 256 + threadIdx.x);
+  if (col >= N) return;
+  const bool full = col + 3 < N;
+  float acc[RT][4];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) { acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f; }
+  for (int j = 0; j < s; ++j) {
+    const float* src = Y + (long long)j * ldy + col;
+    float y0, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+    if (full) { const f4u v = *reinterpret_cast<const f4u*>(src); y0 = v[0]; y1 = v[1]; y2 = v[2]; y3 = v[3]; }
+    else { y0 = src[0]; if (col + 1 < N) y1 = src[1]; if (col + 2 < N) y2 = src[2]; }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float c = cs[t * s + j];
+      acc[t][0] += c * y0; acc[t][1] += c * y1; acc[t][2] += c * y2; acc[t][3] += c * y3;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    if (r0 + t >= r) break;
+    float* dst = Out + (long long)(r0 + t) * ldo + col;
+    if (Z) {
+      const float* zs = Z + (long long)(r0 + t) * ldz + col;
+      acc[t][0] += zscale * zs[0];
+      if (col + 1 < N) acc[t][1] += zscale * zs[1];
+      if (col + 2 < N) acc[t][2] += zscale * zs[2];
+      if (col + 3 < N) acc[t][3] += zscale * zs[3];
+    }
+    if (full) { f4u v; v[0] = acc[t][0]; v[1] = acc[t][1]; v[2] = acc[t][2]; v[3] = acc[t][3]; *reinterpret_cast<f4u*>(dst) = v; }
+    else { dst[0] = acc[t][0]; if (col + 1 < N) dst[1] = acc[t][1]; if (col + 2 < N) dst[2] = acc[t][2]; }
+  }
+}
+
 // ---- counter-based RNG: Philox4x32-10, counter = flat element index / 4, key = seed ---------------------------
 __device__ __forceinline__ void philox4x32(unsigned long long ctr, unsigned long long key, unsigned int (&out)[4]) {
   unsigned int c0 = (unsigned int)ctr, c1 = (unsigned int)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
@@ -395,6 +524,45 @@ int lip_cg_direction(float* p, const float* r, const float* rr_new, const float*
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(cg_direction_kernel, dim3(nblk_for(N, CHUNK, 2048), P), dim3(KT), 0, st, p, r, rr_new, rr_old,
                      (const int*)active, (long long)N);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+
+int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64_t ldb, int32_t n, int64_t K, double* C,
+                   void* stream) {
+  if (!A || !B || !C || m <= 0 || n <= 0 || K <= 0 || lda < K || ldb < K) { set_error("lip_dot_nt_f64: bad argument"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  LIP_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(double) * (size_t)m * n, st));
+  const long long tiles = (long long)((m + DT_B - 1) / DT_B) * ((n + DT_B - 1) / DT_B);
+  // split K until the launch has ~2048 blocks, whole 64-chunks per block, at least 16 chunks each
+  long long chunks = (K + DT_KC - 1) / DT_KC, ks = (2048 + tiles - 1) / tiles;
+  if (ks > chunks / 16) ks = chunks / 16;
+  if (ks < 1) ks = 1;
+  if (ks > 65535) ks = 65535;
+  const long long kper = (chunks + ks - 1) / ks * DT_KC;
+  ks = (K + kper - 1) / kper;
+  hipLaunchKernelGGL(dot_nt_f64_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
+                     (long long)ldb, n, (long long)K, kper, C);
+  LIP_CHECK_HIP(hipGetLastError());
+  return LIP_OK;
+}
+
+int lip_rows_combine(const double* Cm, const float* Y, int64_t ldy, int32_t s, const float* Z, int64_t ldz, float zscale,
+                     float* Out, int64_t ldo, int32_t r, int64_t N, void* stream) {
+  if (!Cm || !Y || !Out || s <= 0 || r <= 0 || N <= 0 || ldy < N || ldo < N || (Z && ldz < N) || s > 4096) {
+    set_error("lip_rows_combine: bad argument");
+    return LIP_ERR_ARG;
+  }
+  if (Out == Y || Out == Z) { set_error("lip_rows_combine: the output must not alias an input"); return LIP_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned ny = (unsigned)((N + 1023) / 1024);
+  if (r <= 4)
+    hipLaunchKernelGGL((rows_combine_kernel<4>), dim3((unsigned)((r + 3) / 4), ny), dim3(256), sizeof(float) * 4 * s, st, Cm, Y,
+                       (long long)ldy, s, Z, (long long)ldz, zscale, Out, (long long)ldo, r, (long long)N);
+  else
+    hipLaunchKernelGGL((rows_combine_kernel<12>), dim3((unsigned)((r + 11) / 12), ny), dim3(256), sizeof(float) * 12 * s, st, Cm, Y,
+                       (long long)ldy, s, Z, (long long)ldz, zscale, Out, (long long)ldo, r, (long long)N);
   LIP_CHECK_HIP(hipGetLastError());
   return LIP_OK;
 }

@@ -58,6 +58,72 @@ def fill_normal(P: int, N: int, seed: int, device="cuda", out: Optional[torch.Te
     return X
 
 
+def _rows_f32(X: torch.Tensor):
+    """(rows, N) float32 device matrix whose rows are contiguous (any row stride): (tensor, row stride)."""
+    if not (X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1):
+        raise nv.NativeError("expected a float32 CUDA matrix with contiguous rows (no CPU fallback)")
+    return X, (X.stride(0) if X.shape[0] > 1 else X.shape[1])
+
+
+def dot_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A B^T (m, n) in float64 from float32 rows A (m, K), B (n, K): every product exact, float64 accumulation
+    (``lip_dot_nt_f64``)."""
+    lib = nv.load()
+    A, lda = _rows_f32(A)
+    B, ldb = _rows_f32(B)
+    if A.shape[1] != B.shape[1]:
+        raise ValueError(f"dot_nt: inner dimensions differ ({A.shape[1]} vs {B.shape[1]})")
+    C = torch.empty(A.shape[0], B.shape[0], device=A.device, dtype=torch.float64)
+    nv.check(lib.lip_dot_nt_f64(A.data_ptr(), lda, A.shape[0], B.data_ptr(), ldb, B.shape[0], A.shape[1], C.data_ptr(),
+                                nv.stream_ptr()), "lip_dot_nt_f64")
+    return C
+
+
+def rows_combine(Cm: torch.Tensor, Y: torch.Tensor, Z: Optional[torch.Tensor] = None, zscale: float = 0.0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = zscale * Z[i] + sum_j Cm[i, j] Y[j]: r combinations of the s rows of Y in one streaming pass
+    (``lip_rows_combine``).  Cm (r, s) is taken in float64."""
+    lib = nv.load()
+    Y, ldy = _rows_f32(Y)
+    r, s = Cm.shape
+    if s != Y.shape[0]:
+        raise ValueError(f"rows_combine: {s} coefficients per row for {Y.shape[0]} rows")
+    Cd = Cm.to(device=Y.device, dtype=torch.float64).contiguous()
+    N = Y.shape[1]
+    O = torch.empty(r, N, device=Y.device, dtype=torch.float32) if out is None else out
+    O, ldo = _rows_f32(O)
+    zp, ldz = 0, 0
+    if Z is not None:
+        Z, ldz = _rows_f32(Z)
+        zp = Z.data_ptr()
+    nv.check(lib.lip_rows_combine(Cd.data_ptr(), Y.data_ptr(), ldy, s, zp, ldz, float(zscale), O.data_ptr(), ldo, r, N,
+                                  nv.stream_ptr()), "lip_rows_combine")
+    return O
+
+
+def gram_orthonormalize(Y: torch.Tensor, rtol: float = 1e-10, passes: int = 2) -> torch.Tensor:
+    """Orthonormal rows spanning the rows of Y (s, N), N >> s, without a Householder QR of a tall matrix: the float64
+    Gram G = Y Y^T (``dot_nt``: one read of Y), its s x s eigendecomposition G = U L U^T, Q = L^(-1/2) U^T Y
+    (``rows_combine``: one read + one write) — the CholeskyQR family with the symmetric factor L^(1/2) U^T in place of
+    the Cholesky factor, so a rank-deficient Y (Hutch++ with more probes than dimensions, ``tests/test_stochtrace.py:
+    90-97``) simply yields fewer rows.  Done twice ("CholeskyQR2"): the first pass leaves ||Q Q^T - I|| ~ eps cond(Y)^2,
+    the second brings it to rounding.  12 N s bytes per pass (>= 3 * 4 * D * s).  Replaces
+    ``jnp.linalg.qr`` at ``src/stochtrace.py:128`` (only span(Q) enters the estimator)."""
+    s_rows, N = Y.shape
+    if s_rows > 384 or N < 4 * s_rows:
+        # not tall-skinny (the reference's own "more probes than dimensions" test): Householder QR in float64
+        Qf, _ = torch.linalg.qr(Y.T.double(), mode="reduced")
+        return Qf.T.float().contiguous()
+    Q = Y
+    for it in range(passes):
+        G = dot_nt(Q, Q)
+        ev, U = torch.linalg.eigh(0.5 * (G + G.T))
+        keep = ev > (rtol if it == 0 else 0.25) * ev.max().clamp_min(1e-300)
+        Cm = (U[:, keep] * torch.rsqrt(ev[keep])).T
+        Q = rows_combine(Cm, Q)
+    return Q
+
+
 def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Tensor, k: int
                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """k-step Lanczos with full re-orthogonalisation, P recurrences at once.

@@ -45,7 +45,15 @@ def _seed(key) -> int:
     return int(key)
 
 
-GRAM_RTOL = 1e-6
+# Eigenvalues of the Gram W^T W at or below rtol * max are treated as exact zeros (the classifier's Gram has rank
+# M (K - 1)).  A dropped direction is sampled with the PRIOR variance 1/alpha instead of
+# 1/(alpha + beta lambda), so the threshold has to sit at the noise floor of the Gram, not above it: 1e-12 for the
+# float64-accumulated Gram of the materialised float32 factor (its null eigenvalues come out at ~eps_f32^2 = 4e-15 of
+# the top one), 1e-6 for a Gram assembled from float32 engine outputs (matrix-free route; noise ~1e-6 of the top one).
+# (With 1e-6 everywhere the XOR config, alpha = 9e-4, drew 1 % too much energy: beta lambda of the dropped directions
+# was up to ten times alpha.)
+GRAM_RTOL = 1e-12
+GRAM_RTOL_F32 = 1e-6
 
 
 def _psd_and_pinv(G: torch.Tensor, rtol: float = GRAM_RTOL, return_eig: bool = False):
@@ -63,8 +71,35 @@ def _pinv_sym(G: torch.Tensor, rtol: float = GRAM_RTOL) -> torch.Tensor:
     return _psd_and_pinv(G, rtol)[1]
 
 
+def orthonormal_factor(Wm: torch.Tensor, ev: torch.Tensor, Ug: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
+    """Qm (r, D): rows q_k = lambda_k^(-1/2) sum_i Ug[i, k] Wm[i] for the kept eigenpairs of the Gram Wm Wm^T = Ug diag(ev)
+    Ug^T — an orthonormal basis of range(W) in which W W^T = sum_k lambda_k q_k q_k^T.  The combination is formed in
+    float64 (column slabs of the factor, one float64 GEMM each) and rounded once: a float32 GEMM would leave the stiff
+    directions accurate to ~1e-6 only, and the sampler needs them to ~1e-7 (see ``_SamplerParts``)."""
+    C = (Ug[:, keep] * torch.rsqrt(ev[keep])).T.contiguous()              # (r, d) float64
+    r, D = C.shape[0], Wm.shape[1]
+    Qm = torch.empty(r, D, device=Wm.device, dtype=torch.float32)
+    slab = 1 << 16
+    for c in range(0, D, slab):
+        Qm[:, c:c + slab] = (C @ Wm[:, c:c + slab].double()).float()
+    return Qm
+
+
 class _SamplerParts:
-    """Everything ``inv_matsqrt_vp`` precomputes once per (state, Z, alpha)."""
+    """Everything ``inv_matsqrt_vp`` precomputes once per (state, Z, alpha).
+
+    ``method="eigh"`` with a materialised factor applies A^(-1/2) in the eigenbasis of the Gram: with
+    W W^T = sum_k lambda_k q_k q_k^T (q_k orthonormal, the rows of ``Qm``) the reference's formula
+    (``src/sample.py:78-85,130-143``) collapses to
+
+        A^(-1/2) v = alpha^(-1/2) v + sum_k q_k (f(alpha + beta lambda_k) - alpha^(-1/2)) <q_k, v> .
+
+    The literal form W (W^T W)^+ [f(A_d) - alpha^(-1/2)] W^T v is numerically hopeless in float32 at the CIFAR config
+    (cond(A) = 3e9): the d x d matrix in the middle spans six decades, so its float32 image no longer contains the
+    stiff directions at all, and the stiff component of a draw — 1.8e-5 of the alpha^(-1/2) v it cancels against —
+    came out with O(1) relative error (measured through the matrix-free operator: whitening error 2.4e-3 of ||v||^2;
+    4e-5 in this form).  Here every quantity is O(|v|): the coefficients <q_k, v> come from one float32 GEMM, are
+    scaled in float64, and the second GEMM adds the correction to alpha^(-1/2) v in its epilogue."""
 
     def __init__(self, state, Z, D, alpha, model_type, full_set_size, clip_min, method):
         self.Wfun, self.WTfun = compute_W_vps(state, Z, model_type, full_set_size=None)   # :64
@@ -77,7 +112,7 @@ class _SamplerParts:
         self.d = math.prod(self.inner)
         # In the inducing-point regime the factor Wm (d, D) fits in HBM: materialise it once (d backward rows),
         # take the Gram from it and apply W^T / W as plain GEMMs.  Otherwise stay matrix-free throughout.
-        self.Wm = None
+        self.Wm = self.Qm = None
         if self.d * eng.D * 4 <= FACTOR_BYTES_LIMIT:
             c = math.sqrt(1.0) * (math.exp(-0.5 * float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0)
             self.Wm = materialize_factor(eng, c)
@@ -85,7 +120,7 @@ class _SamplerParts:
             G64 = torch.triu(G64) + torch.triu(G64, 1).T                                                 # :227
         else:
             G64 = build_WTW(self.Wfun, self.WTfun, self.inner, self.d, dtype=torch.float64, block=2)    # :77
-        G_psd, G_pinv, evp, Ug = _psd_and_pinv(G64, return_eig=True)
+        G_psd, G_pinv, evp, Ug = _psd_and_pinv(G64, GRAM_RTOL if self.Wm is not None else GRAM_RTOL_F32, return_eig=True)
         self.WTW = G_psd.float().contiguous()
         self.G_pinv = G_pinv.float().contiguous()
         A64 = self.alpha * torch.eye(self.d, device=eng.device, dtype=torch.float64) + self.beta * G_psd
@@ -97,47 +132,74 @@ class _SamplerParts:
             self.funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(f, clip_min, floor=self.alpha), self.depth)   # :113-115
         elif method == "eigh":
             # alpha I + beta G_psd shares G_psd's eigenvectors: f(A) from the decomposition already at hand
+            keep = evp > 0
             lamA = torch.clamp(self.alpha + self.beta * evp, min=self.alpha)
             if clip_min is not None:
                 lamA = torch.clamp(lamA, min=clip_min)
-            self.fA = ((Ug * f(lamA)) @ Ug.T).float().contiguous()
+                g = f(lamA) - 1.0 / math.sqrt(self.alpha)
+            else:
+                # f(alpha + beta lambda) - alpha^(-1/2) in its cancellation-free form
+                sa, sl = math.sqrt(self.alpha), torch.sqrt(lamA)
+                g = -self.beta * evp / (sa * sl * (sa + sl))
+            # the same operator in W^T-coordinates, for the matrix-free fallback:  X = U Mc,  out = W X + a v
+            h = torch.where(keep, g / evp.clamp_min(1e-300), torch.zeros_like(g))
+            self.Mc64 = ((Ug * h) @ Ug.T).contiguous()
+            order = torch.argsort(g[keep])                  # most negative first = stiffest direction first
+            kept = torch.nonzero(keep).flatten()[order]     # index form: rows of Qm sorted by stiffness
+            self.g = g[kept].contiguous()                                                   # (r,) float64
+            # <q_k, v> is needed to alpha^(1/2) (alpha + beta lambda_k)^(-1/2) * tol RELATIVE accuracy (the draw's stiff
+            # component is that fraction of the alpha^(-1/2) <q_k, v> it cancels against): a float32-accumulated GEMM
+            # over D = 1e6 delivers ~4e-6, enough for directions with sqrt((alpha + beta lambda) / alpha) < 250 at
+            # tol = 1e-3; the stiffer ones (at most 96, first in the sorted order) get float64-accumulated coefficients
+            stiff = torch.sqrt(lamA[kept] / self.alpha) > 250.0
+            self.n_stiff = int(min(96, int(stiff.sum().item())))
+            if self.Wm is not None:
+                self.Qm = orthonormal_factor(self.Wm, evp, Ug, kept)
         else:
             raise ValueError("method must be 'lanczos' or 'eigh'")
 
     def f_small(self, U: torch.Tensor) -> torch.Tensor:
-        """f(alpha I + beta W^T W) applied to the rows of U (S, d)."""
-        if self.method == "eigh":
-            return U @ self.fA
-        return self.funm(lambda X: X @ self.A_d, U.contiguous())                           # :117-128
+        """f(alpha I + beta W^T W) applied to the rows of U (S, d) — the reference's small-space Lanczos (:117-128)."""
+        return self.funm(lambda X: X @ self.A_d, U.contiguous())
 
-    def apply(self, V: torch.Tensor) -> torch.Tensor:
-        """rows of V (S, D) -> A^(-1/2) V"""
+    def _correction(self, V: torch.Tensor):
+        """(T, B) with  A^(-1/2) V = alpha^(-1/2) V + T B  (T small and float32, B the (rows, D) factor it multiplies)."""
         S = V.shape[0]
+        a = 1.0 / math.sqrt(self.alpha)
+        if self.method == "eigh" and self.Qm is not None:
+            C = (V @ self.Qm.T).double()                                                   # <q_k, v>: one GEMM pass
+            if self.n_stiff:
+                C[:, :self.n_stiff] = krylov.dot_nt(V, self.Qm[:self.n_stiff])             # float64-accumulated
+            return (C * self.g).float().contiguous(), self.Qm
         if self.Wm is not None:
             U = V @ self.Wm.T                                                              # W^T v as a GEMM
         else:
             U = self.WTfun.rows(V).reshape(S, self.d)                                      # W^T v, matrix-free
-        x1 = self.f_small(U) @ self.G_pinv                                                 # :130-138
-        x2 = U @ self.G_pinv                                                               # :78-84
-        a = 1.0 / math.sqrt(self.alpha)
-        X = (x1 - a * x2).contiguous()
-        if self.Wm is not None:
-            out = X @ self.Wm                                                              # W x as a GEMM
+        if self.method == "eigh":
+            X = (U.double() @ self.Mc64).float().contiguous()                              # :78-84 and :130-138 fused
         else:
-            out = self.Wfun.rows(X.reshape((S,) + self.inner))                             # one W sweep
-        return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
+            x1 = self.f_small(U) @ self.G_pinv                                             # :130-138
+            x2 = U @ self.G_pinv                                                           # :78-84
+            X = (x1 - a * x2).contiguous()
+        return X, self.Wm
 
+    def apply(self, V: torch.Tensor) -> torch.Tensor:
+        """rows of V (S, D) -> A^(-1/2) V"""
+        T, B = self._correction(V)
+        a = 1.0 / math.sqrt(self.alpha)
+        if B is not None:
+            return torch.addmm(V, T, B, beta=a, alpha=1.0)                                 # W x + alpha^(-1/2) v in one pass
+        out = self.Wfun.rows(T.reshape((V.shape[0],) + self.inner))                        # one W sweep, matrix-free
+        return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
 
     def apply_(self, V: torch.Tensor) -> torch.Tensor:
         """In-place :meth:`apply` for the materialised-factor case: the ``+ alpha^(-1/2) v`` term rides in the second
-        GEMM's epilogue (``beta * C``), so a block of draws costs two GEMM passes over Wm and nothing else."""
-        if self.Wm is None:
+        GEMM's epilogue (``beta * C``), so a block of draws costs two GEMM passes over the factor and nothing else."""
+        T, B = self._correction(V)
+        if B is None:
             V.copy_(self.apply(V))
             return V
-        U = V @ self.Wm.T
-        G = self.G_pinv
-        X = (self.f_small(U) @ G - (1.0 / math.sqrt(self.alpha)) * (U @ G)).contiguous()
-        return torch.addmm(V, X, self.Wm, beta=1.0 / math.sqrt(self.alpha), alpha=1.0, out=V)
+        return torch.addmm(V, T, B, beta=1.0 / math.sqrt(self.alpha), alpha=1.0, out=V)
 
 
 _PARTS_CACHE = {}

@@ -18,7 +18,7 @@ from .ggn import build_WTW, compute_W_vps
 from .matfree import dense_funm_sym_eigh, funm_lanczos_sym, tridiag_sym
 
 REFERENCE_CLIP_MIN = 1.0
-PRODUCT_GRAM_RTOL = 1e-6
+PRODUCT_GRAM_RTOL = 1e-12
 
 
 def _gram_solver(WTW, gram_rtol):

@@ -1,0 +1,119 @@
+"""BASELINE.json configs[1] on its own data: XOR 2-D classification (``data/xor.npz`` of the reference, committed as
+``tests/golden/xor.npz``), ``SimpleClassifier(16, 2, 2)`` (``config/toy/toyclassifier_xor.yml``: M = 32 inducing
+points, alpha = 0.0009), matrix-free GGN-vp over the 1024 training rows (``src/toydata.py:242-256``: the first 80 %),
+64-probe Hutchinson trace, and the Lanczos low-rank posterior (``src/sample.py:55-156``: 2M = 64 small-space Lanczos
+steps) against the dense float64 posterior (D = 354 is dense-feasible).
+
+The MAP weights are trained here (the reference's ``checkpoint/`` is absent): 300 full-batch Adam steps on
+the cross-entropy + L2 prior of ``src/train_map.py:52-80`` in float64 on the CPU, seeded.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from impl import cpu64, impl  # noqa: F401
+from lip_amd.toymodels import SimpleClassifier, create_state
+from lip_amd.utils import flatten_nn_params
+import oracle.ggn as og
+import oracle.sample as osamp
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F64 = torch.float64
+M_IP, N_TRAIN, D = 32, 1024, 354
+
+
+@pytest.fixture(scope="module")
+def xor():
+    d = np.load(os.path.join(GOLDEN, "xor.npz"))
+    x, y = torch.from_numpy(d["x"]).to(F64), torch.from_numpy(d["y"]).long()
+    assert tuple(x.shape) == (1280, 2)
+    xtr, ytr = x[:N_TRAIN], y[:N_TRAIN]                       # load_toydata: first 80 % is the training split
+    net = SimpleClassifier(16, 2, 2)
+    st = create_state(net, seed=12345, dtype=F64)             # model.seed of the config
+    flat, unravel = flatten_nn_params(st.params)
+    assert flat.numel() == D
+    theta = flat.clone().requires_grad_(True)
+    opt = torch.optim.Adam([theta], lr=0.05)
+    alpha = 0.0009
+    for _ in range(300):
+        opt.zero_grad()
+        logits = net.forward({"params": unravel(theta)["params"]}, {}, xtr)
+        loss = torch.nn.functional.cross_entropy(logits, ytr, reduction="sum") + 0.5 * alpha * (theta ** 2).sum()
+        loss.backward()
+        opt.step()
+    acc = (net.forward({"params": unravel(theta.detach())["params"]}, {}, xtr).argmax(-1) == ytr).double().mean().item()
+    assert acc > 0.9, f"MAP fit of the XOR net failed (train accuracy {acc})"
+    st = st.replace(params={"params": unravel(theta.detach().clone())["params"]})
+    Z = xtr[:M_IP].clone()
+    return dict(st=st, xtr=xtr, Z=Z, alpha=alpha)
+
+
+def test_xor_ggn_vp_and_hutchinson_trace(impl, xor):
+    st, X = xor["st"], xor["xtr"]
+    GGN, *_ = og.compute_ggn_dense(st, X, "classifier")
+    P = 64 if impl.is_hip else 3                              # the oracle's per-example loop: 1024 jvp+vjp per probe
+    V = torch.sign(torch.randn(P, D, dtype=F64, generator=torch.Generator().manual_seed(5)))
+    vp = impl.ggn.compute_ggn_vp(impl.state(st), impl.tensor(X), "classifier")
+    Y = cpu64(impl.rows(vp, impl.tensor(V)))
+    ref = V @ GGN
+    assert (Y - ref).abs().max().item() <= impl.tol(1e-9, 5e-5) * ref.abs().max().item()
+    if impl.is_hip:
+        # 64-probe Hutchinson trace (src/stochtrace.py:22-34) on the HIP product: relative std of the estimator is
+        # sqrt(2 sum_{i != j} G_ij^2) / (sqrt(P) tr G) — asserted at 4 of those, plus the f32 error of the products
+        tr = float(impl.stochtrace.stochastic_trace_estimator_mvp(vp, D, seed=7, num_samples=64))
+        off = GGN - torch.diag(GGN.diagonal())
+        std = math.sqrt(2.0 * (off ** 2).sum().item() / 64)
+        assert abs(tr - GGN.trace().item()) <= 4.0 * std + 1e-4 * GGN.trace().item()
+
+
+@pytest.mark.parametrize("alpha", [0.0009, 0.5])
+def test_xor_lanczos_posterior_matches_dense(impl, xor, alpha):
+    """v -> (GGN_Z * N/M + alpha I)^(-1/2) v through the reference's low-rank route (Gram of the 32 inducing points,
+    2M = 64 Lanczos steps in the d = 64 space = the full space, so the route is exact up to rounding)."""
+    st, Z = xor["st"], xor["Z"]
+    GGN, *_ = og.compute_ggn_dense(st, Z, "classifier", full_set_size=N_TRAIN)
+    ev, U = torch.linalg.eigh(GGN + alpha * torch.eye(D, dtype=F64))
+    A_inv_sqrt = (U * ev.rsqrt()) @ U.T
+    V = torch.randn(6, D, dtype=F64, generator=torch.Generator().manual_seed(11))
+    ref = V @ A_inv_sqrt
+    if impl.is_hip:
+        outs = {}
+        for method in ("lanczos", "eigh"):
+            fun = impl.sample.inv_matsqrt_vp(impl.state(st), impl.tensor(Z), D, alpha, "classifier",
+                                             full_set_size=N_TRAIN, method=method)
+            assert fun.parts.depth == 64
+            outs[method] = cpu64(fun.rows(impl.tensor(V)))
+    else:
+        fun = osamp.inv_matsqrt_vp(st, Z, D, alpha, "classifier", full_set_size=N_TRAIN, clip_min=None,
+                                   gram_rtol=osamp.PRODUCT_GRAM_RTOL)
+        outs = {"lanczos": torch.stack([fun(v) for v in V])}
+    # float64 oracle: the truncated pseudo-inverse (rtol 1e-12 on the Gram spectrum) drops directions that carry
+    # <= 1e-12 of the top curvature, whose contribution differs from alpha^(-1/2) v by O(beta lambda / alpha) relative:
+    # 1e-12 * cond; fp32: the same plus eps * sqrt(cond) rounding of the range part
+    lam_max = (ev.max() - alpha).item()
+    drop = 1e-12 * lam_max / alpha                                       # relative weight of a dropped direction
+    tol = max(impl.tol(1e-7, 2e-4), 2.0 * drop) * ref.abs().max().item()
+    for method, out in outs.items():
+        assert (out - ref).abs().max().item() <= tol, (method, (out - ref).abs().max().item(), tol)
+
+
+def test_xor_samples_have_posterior_covariance(impl, xor):
+    """``sample`` (zero-mean draws, src/sample.py:148-156) at the config's alpha against the dense posterior
+    N(0, (GGN_Z N/M + alpha I)^-1): energy identity mean_s x_s^T A x_s / D = 1 (std sqrt(2 / (S D))) and the
+    per-coordinate standard deviations (reference tests/test_sample.py:478-479 compare these at atol 1e-1)."""
+    st, Z, alpha = xor["st"], xor["Z"], xor["alpha"]
+    GGN, *_ = og.compute_ggn_dense(st, Z, "classifier", full_set_size=N_TRAIN)
+    A = GGN + alpha * torch.eye(D, dtype=F64)
+    S = 4000 if impl.is_hip else 40
+    kw = {} if impl.is_hip else dict(gram_rtol=osamp.PRODUCT_GRAM_RTOL, clip_min=None)
+    X = cpu64(impl.sample.sample(impl.state(st), impl.tensor(Z), D, alpha=alpha, key=1392, model_type="classifier",
+                                 num_samples=S, full_set_size=N_TRAIN, **kw))
+    assert tuple(X.shape) == (S, D) and torch.isfinite(X).all()
+    energy = ((X @ A) * X).sum(1).mean().item() / D
+    assert abs(energy - 1.0) <= 5.0 * math.sqrt(2.0 / (S * D)) + 1e-3
+    if impl.is_hip:
+        sd_ref = torch.linalg.inv(A).diagonal().sqrt()
+        assert torch.allclose(X.std(0), sd_ref, rtol=5.0 / math.sqrt(2 * S) + 1e-2)

@@ -95,3 +95,49 @@ def test_fill_statistics_and_determinism():
     nv.check(lib.lip_fill_normal(nv.ptr(A), P, N, 99, nv.stream_ptr()), "normal")
     assert abs(A.mean().item()) < 0.01 and abs(A.std().item() - 1.0) < 0.01
     assert abs((A ** 4).mean().item() - 3.0) < 0.1
+
+
+@pytest.mark.parametrize("m,n,K", [(1, 1, 1), (3, 5, 241), (8, 33, 4099), (40, 40, 100003), (70, 9, 1084586)])
+def test_dot_nt_f64(m, n, K):
+    """float64-accumulated A B^T of float32 rows: exact to float64 rounding — including unaligned rows (odd K as the
+    row stride) and strided row views."""
+    from lip_amd import krylov
+    A, B = _blk(m, K, 11), _blk(n, K, 12)
+    C = krylov.dot_nt(A, B)
+    ref = A.double() @ B.double().T
+    assert C.dtype == torch.float64 and tuple(C.shape) == (m, n)
+    assert torch.allclose(C, ref, rtol=1e-12, atol=1e-12 * K ** 0.5)
+    if K > 8:
+        Av = _blk(m, K + 3, 13)[:, 1:K + 1]                    # rows at stride K + 3, base offset by one float
+        assert torch.allclose(krylov.dot_nt(Av, B), Av.double() @ B.double().T, rtol=1e-12, atol=1e-12 * K ** 0.5)
+
+
+@pytest.mark.parametrize("r,s,N", [(1, 1, 1), (3, 7, 241), (13, 20, 4099), (36, 36, 100003), (5, 300, 70001)])
+def test_rows_combine(r, s, N):
+    from lip_amd import krylov
+    Y, Z = _blk(s, N, 21), _blk(r, N, 22)
+    Cm = torch.randn(r, s, dtype=torch.float64, generator=torch.Generator().manual_seed(23)).cuda()
+    out = krylov.rows_combine(Cm, Y)
+    ref = Cm @ Y.double()
+    tol = 2e-6 * (s ** 0.5) * ref.abs().max().item()
+    assert (out.double() - ref).abs().max().item() <= tol
+    out2 = krylov.rows_combine(Cm, Y, Z=Z, zscale=-0.5)
+    assert (out2.double() - (ref - 0.5 * Z.double())).abs().max().item() <= tol + 1e-6
+
+
+@pytest.mark.parametrize("s,N,rank", [(20, 100003, 20), (36, 1084586, 36), (12, 5000, 7)])
+def test_gram_orthonormalize(s, N, rank):
+    """CholeskyQR2-style orthonormalisation on the HIP kernels: orthonormal to float32 rounding, same span as the
+    input rows, and a rank-deficient block yields rank rows."""
+    from lip_amd import krylov
+    Y = _blk(rank, N, 31)
+    Y = Y * torch.logspace(0, 3, rank, device="cuda")[:, None]          # cond(Y) = 1e3
+    if rank < s:
+        mix = torch.randn(s, rank, generator=torch.Generator().manual_seed(32)).cuda()
+        Y = (mix.double() @ Y.double()).float()
+    Q = krylov.gram_orthonormalize(Y)
+    assert Q.shape[0] == rank
+    G = Q.double() @ Q.double().T
+    assert (G - torch.eye(rank, device="cuda", dtype=torch.float64)).abs().max().item() <= 2e-6
+    proj = Y.double() - (Y.double() @ Q.double().T) @ Q.double()     # rows of Y lie in span(Q)
+    assert proj.norm().item() <= 1e-5 * Y.double().norm().item()
