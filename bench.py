@@ -208,6 +208,13 @@ def main():
         eng.ggn_vp(V, scale, alpha)
     prof = eng.profile_read()
     eng.profile(False)
+    # one-off primal forward of the binding (reported separately; 2 MACs_fwd FLOP per example)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        nv.check(eng.lib.lip_engine_primal(eng.h, nv.stream_ptr()), "lip_engine_primal")
+    torch.cuda.synchronize()
+    primal_ms = 1e3 * (time.perf_counter() - t1) / 5
     flops = eng.flops_per_probe()
     kinds = {nv.OP_IGEMM: "igemm_kernel", nv.OP_WGRAD: "wgrad_kernel"}
     per_kernel = {}
@@ -222,15 +229,17 @@ def main():
     achieved = per_kernel[dom]["tflops"]
     traffic = None
     try:                       # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["kernels"]
+        tj_path = next(pth for pth in (os.path.join(ROOT, "profiles", f) for f in ("r2_traffic.json", "r1_traffic.json")) if os.path.exists(pth))
+        tj = json.load(open(tj_path))["kernels"]
         sel = [v for k, v in tj.items() if "igemm" in k]
         traffic = dict(value=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / sum(v["launches"] for v in sel),
-                       unit="bytes per igemm launch (2 x FETCH_SIZE + WRITE_SIZE)", source="profiles/r1_traffic.json")
+                       unit="bytes per igemm launch (2 x FETCH_SIZE + WRITE_SIZE)", source=os.path.relpath(tj_path, ROOT))
     except Exception:
         pass
     roofline = dict(bound="mfma", kernel=dom + " (tangent-forward + data-gradient implicit GEMMs, f32 MFMA)",
                     achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TFLOPS,
                     traffic=traffic, per_kernel=per_kernel, other_kernels_ms_per_step=other_ms,
+                    primal_pass_ms=primal_ms, primal_pass_tflops=2 * net.macs_per_example() * n / (primal_ms * 1e-3) / 1e12,
                     whole_sweep_tflops=sum(flops.values()) * P / (ms_per_step * 1e-3) / 1e12,
                     flop_model="algorithmic FLOPs from the op tapes: conv segment 2*R*N*Ktot, data-gradient segment "
                                "2*MACs of its conv, WGRAD 2*R*N*M (= 8*MACs_fwd per example-probe minus the input "
@@ -268,8 +277,24 @@ def main():
             tt = torch.tensor([ts, ts2], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ts, ts2 = float(tt[0].item()), float(tt[1].item())
+        parts = next(iter(_smod._PARTS_CACHE.values()))
+        r_dirs, n_stiff, blk = int(parts.Qm.shape[0]), int(parts.n_stiff), 256
+        # per block of 256 draws on the bound sampler: two GEMM passes over the orthonormalised factor Qm (r, D) —
+        # <q_k, eps> and eps * a + T Qm — plus the float64-accumulated pass over the n_stiff stiffest rows
+        blk_s = ts2 * blk / 2000
+        s_flops = 4.0 * blk * r_dirs * eng.D + 2.0 * blk * n_stiff * eng.D
+        s_bytes = 4.0 * eng.D * (2 * r_dirs + 2 * blk)           # 2 passes over the factor + read eps + write the draw
+        samples_roofline = dict(
+            block=blk, rows_of_factor=r_dirs, stiff_rows_f64=n_stiff, ms_per_block=1e3 * blk_s,
+            tflops=s_flops / blk_s / 1e12, frac_of_f32_mfma_peak=s_flops / blk_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            algorithmic_GBps=s_bytes / blk_s / 1e9, frac_of_hbm_peak=s_bytes / blk_s / 1e9 / 8000.0,
+            bound="mfma (arithmetic intensity %.0f FLOP/B against a machine balance of 19.7)" % (s_flops / s_bytes),
+            kernels="the two (256 x r x D) passes are library GEMMs (hipBLASLt through torch.addmm); hand-written: the "
+                    "factor rows (lip_vjp_rows), the float64-accumulated stiff coefficients (lip_dot_nt_f64), the Philox "
+                    "normal fill",
+            model="FLOPs 4 S r D + 2 S n_stiff D; bytes 4 D (2 r + 2 S) = two passes over the factor + read eps + write out")
         samples_line = dict(value=world * args.samples / ts, unit="posterior samples/s", num_samples=world * args.samples,
-                            seconds=ts, at_2000_samples_same_binding=world * 2000 / ts2, ranks=world,
+                            seconds=ts, at_2000_samples_same_binding=world * 2000 / ts2, ranks=world, roofline=samples_roofline,
                             includes="fresh (state, Z) binding: engine build + primal pass + factor rows (one per-example "
                                      "backward sweep of K probes) + float64 Gram + exact small-space f(A), then W^T / W "
                                      "as GEMMs; the second figure reuses the binding (2000 draws)",
@@ -345,6 +370,30 @@ def main():
                         note="224x224x3 inputs, torchvision-style bottleneck ResNet-50, random init; a slice of configs[4] "
                              "(1024 probes x 10k images over 8 GPUs = 160 such blocks x 16 probe chunks per GPU)")
         del e50, V50, Y50
+        torch.cuda.empty_cache()
+        # the data sum over MANY images: 256 images as 32 chunks of 8 behind one shared probe workspace
+        # (ExampleChunkedGGN — the single-GPU twin of the 8-GPU shard of configs[4]), 16 probes
+        from lip_amd.ggn import ExampleChunkedGGN
+        n256, P256 = 256, 16
+        Z256 = torch.rand(n256, 224, 224, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ch = ExampleChunkedGGN(st50.to(device=dev, dtype=torch.float32), Z256, "classifier", full_set_size=10000,
+                               example_chunk=8, workspace_bytes=24 << 30, max_probes=P256)
+        torch.cuda.synchronize()
+        t_bind = time.perf_counter() - t1
+        V256 = krylov.fill_rademacher(P256, ch.D, 12, dev)
+        t1 = time.perf_counter()
+        Y256 = ch(V256, alpha=1.0)
+        torch.cuda.synchronize()
+        t256 = time.perf_counter() - t1
+        r50_line["chunked_256_images"] = dict(
+            images=n256, probes=P256, chunks=len(ch.engines), bind_seconds=t_bind, seconds_per_block=t256,
+            value=P256 / t256, unit="GGN-vp/s over 256 images", tflops=f50 / n50 * n256 * P256 / t256 / 1e12,
+            finite=bool(torch.isfinite(Y256).all().item()),
+            note="10k images x 1024 probes over 8 GPUs = 40 such 256-image sums x 64 probe blocks per GPU")
+        del ch, V256, Y256, Z256
+        torch.cuda.empty_cache()
 
     # ---- the north star's Krylov route: D-space Lanczos on the matrix-free GGN + alpha I (36 matvecs, full re-orth.) ----
     lanczos_line = None
@@ -387,6 +436,61 @@ def main():
                               "(image, draw)", finite=bool(torch.isfinite(LS).all().item()))
         del LS, Xw, Xe
 
+    # ---- trace-estimator legs, end to end (probe fill + block products + quadratic forms) ----------------------
+    trace_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        from lip_amd import stochtrace
+        from lip_amd.ggn import BlockOperator
+        from lip_amd.scalemodels import LargeClassifier
+        trace_line = {}
+
+        def timed(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                out = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps, float(out)
+
+        # configs[2]: MNIST-MLP (784-1024-512-256-128-10 tanh, D = 1 494 154), 50 synthetic inducing images,
+        # 64-probe Girard-Hutchinson trace of GGN + alpha I  (src/stochtrace.py:22-34)
+        mlp = LargeClassifier((28, 28, 1), [1024, 512, 256, 128], 4, 10)
+        st_m = create_state(mlp, seed=12345, dtype=torch.float32)
+        Zm = torch.rand(50, 28, 28, 1, generator=torch.Generator().manual_seed(5)).to(dev)
+        em = LinearizedNet(st_m, Zm, "classifier", device=dev, workspace_bytes=2 << 30, max_chunk=64)
+        op_m = BlockOperator(lambda B: em.ggn_vp(B, 1.0, 1e-3), (em.D,), (em.D,), em, "mnist")
+        t_m, tr_m = timed(lambda: stochtrace.stochastic_trace_estimator_mvp(op_m, em.D, 11, num_samples=64, device=dev))
+        fl_m = sum(em.flops_per_probe().values()) * 64
+        by_m = 4.0 * em.D * 64 * 4                      # write eps, read eps (tangent weights), write Y, read eps . Y
+        trace_line["hutchinson_mnist_mlp_64"] = dict(
+            seconds=t_m, trace=tr_m, D=em.D, probes=64, examples=50, tflops=fl_m / t_m / 1e12,
+            algorithmic_GBps=by_m / t_m / 1e9, frac_of_hbm_peak=by_m / t_m / 1e9 / 8000.0,
+            frac_of_f32_mfma_peak=fl_m / t_m / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            note="BASELINE configs[2] (synthetic 28x28 inputs: the MNIST blob is absent): 64 Rademacher probes, one block "
+                 "product, 64 dots; per probe the sweep reads its D tangent weights and writes its D cotangents, so this "
+                 "small net is HBM-bound: bytes = 4 passes over the (64, D) block")
+        del em, op_m, Zm
+        # configs[3]: Hutch++ (s1 = 20, s2 = 16 as src/train_inducing.py:139-146 at st_samples = 36) on the CIFAR
+        # binding of the headline: 2 s1 + s2 = 56 products as three blocks + the tall-skinny orthonormalisation
+        op_c = BlockOperator(lambda B: eng.ggn_vp(B, scale, alpha), (eng.D,), (eng.D,), eng, "cifar")
+        probes36 = krylov.fill_rademacher(36, eng.D, 21, dev)
+        t_h, tr_h = timed(lambda: stochtrace.hutchpp_v2(op_c, lambda _: probes36, s1=20, s2=16))
+        Y20 = op_c.rows(probes36[:20])
+        t_q, _ = timed(lambda: krylov.gram_orthonormalize(Y20).sum(), reps=5)
+        t_mv, _ = timed(lambda: op_c.rows(probes36[:20]).sum() + op_c.rows(probes36[:20]).sum() + op_c.rows(probes36[20:]).sum(), reps=2)
+        qr_bytes = 2 * 12.0 * eng.D * 20                # two passes of (read for the Gram, read + write for the combination)
+        trace_line["hutchpp_v2_cifar_s1_20_s2_16"] = dict(
+            seconds=t_h, trace=tr_h, products=56, products_seconds=t_mv, orthonormalisation_seconds=t_q,
+            orthonormalisation_GBps=qr_bytes / t_q / 1e9, orthonormalisation_frac_of_hbm_peak=qr_bytes / t_q / 1e9 / 8000.0,
+            note="BASELINE configs[3]: hutchpp_v2 on GGN + alpha I over the 50 inducing images; the (D x 20) QR of "
+                 "src/stochtrace.py:128 runs as a Gram orthonormalisation on lip_dot_nt_f64 + lip_rows_combine, twice: "
+                 "bytes 2 x 12 D s (SURVEY 8d: >= 12 D s per pass); Hutchinson with 256 probes on the same binding is the "
+                 "headline step plus 256 dots")
+        t_256, tr_256 = timed(lambda: stochtrace.stochastic_trace_estimator_mvp(op_c, eng.D, 13, num_samples=256, device=dev), reps=2)
+        trace_line["hutchinson_cifar_256"] = dict(seconds=t_256, trace=tr_256, probes=256,
+                                                  note="fill 256 Rademacher probes + one block product + 256 dots")
+
     krylov_line = None
     if args.samples > 0 and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -394,12 +498,22 @@ def main():
         del eng.work                                   # release the 6.7 GB probe workspace first
         torch.cuda.empty_cache()
         kb = krylov_bench.run(D=1084586, P=256, k=36)
+        lz = kb["lanczos_step_cgs2"]["j=35"]
         krylov_line = dict(bound="hbm", peak=8000.0, unit="GB/s",
-                           cg_step=kb["cg_step"]["GBps"], lanczos_step_j35=kb["lanczos_step_cgs2"]["j=35"]["GBps"],
+                           cg_step=kb["cg_step"]["GBps"], lanczos_step_j35=lz["GBps"],
+                           lanczos_step_j35_frac_traffic=lz["GBps"] / 8000.0,
+                           lanczos_step_j35_frac_survey_model=lz["GBps_survey_model"] / 8000.0,
+                           lanczos_note="two fractions: against the bytes the two-phase algorithm must move (each of the "
+                                        "two Gram-Schmidt passes reads the basis twice: the projection Q^T w is a full-"
+                                        "length reduction that has to finish before w - Q c can start, and the basis — "
+                                        "k x 4.3 MB per probe — does not fit on chip), and against SURVEY 8d's "
+                                        "4 D (7 + 2 j), which counts one read of the basis per pass",
+                           dot_nt_f64=kb["dot_nt_f64"], rows_combine=kb["rows_combine"],
                            hutchinson_dot=kb["bdot"]["GBps"], axpby=kb["axpby"]["GBps"],
                            fill_rademacher=kb["fill_rademacher"]["GBps"],
                            frac_cg_step=kb["cg_step"]["GBps"] / 8000.0,
-                           bytes_model="CG step 44*D B, Lanczos step j with CGS2 4*D*(4*(j+2)+4) B, dot 8*D B per probe")
+                           bytes_model="CG step 44*D B, Lanczos step j with CGS2 4*D*(4*(j+2)+4) B (traffic) / 4*D*(7+2j) B (SURVEY), "
+                                       "dot 8*D B per probe")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -422,7 +536,7 @@ def main():
                                           "example_probe_products_per_s = value * examples_total is the figure that "
                                           "grows with N under weak scaling",
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, trace_estimators=trace_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:

@@ -249,17 +249,21 @@ __global__ __launch_bounds__(KT) void cg_direction_kernel(float* Pd, const float
 // <q_k, v> of the sampler's stiff directions (cond(A) ~ 3e9: a float32-accumulated dot of length 1e6 is two decades too
 // coarse there), the Gram Y Y^T of CholeskyQR2 / Hutch++ (src/stochtrace.py:124-133), the projections G Q^T.
 // Every f32 x f32 product is exact in float64, so the result carries one rounding per addition at 1e-16.
-// Block = 32 x 32 output tile x one K-range; K-chunks of 64 are staged k-major in LDS (transposed on the way in), each
-// of the four waves takes 16 of the 64 k's with a 4 x 4 micro-tile per lane (two ds_read_b128 per 16 v_fma_f64), the
-// waves' partial tiles meet in LDS and leave as ONE float64 atomic per output element and block.
-constexpr int DT_B = 32, DT_KC = 64, DT_LD = DT_B + 4;
+// gfx950 has no faster float64 matrix path than v_fma_f64 (78.6 TF either way), so this is a VALU kernel:
+// block = 32 x 32 output tile x one K-range; K-chunks of 32 are converted to float64 once, on their way into k-major
+// LDS tiles (the next chunk's global loads are in flight during the sweep); each of the four waves takes 8 of the 32
+// k's with a 4 x 4 micro-tile per lane (four ds_read_b128 per 16 v_fma_f64); the waves' partial tiles meet in LDS.
+// Few output tiles mean hundreds of K-ranges per tile: their partial tiles go to a scratch buffer and a second, tiny
+// kernel adds them (float64 atomics on one 32 x 32 tile serialise: 1059 adds per address cost more than the sweep).
+constexpr int DT_B = 32, DT_KC = 32, DT_LD = DT_B + 2;
+constexpr long long DT_SCRATCH_TILES = 4096;          // partial tiles the scratch buffer holds (32 MiB of float64)
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 __global__ __launch_bounds__(256) void dot_nt_f64_kernel(const float* __restrict__ A, long long lda, int m,
                                                          const float* __restrict__ B, long long ldb, int n, long long K,
-                                                         long long kper, double* __restrict__ C) {
-  __shared__ __attribute__((aligned(16))) float As[DT_KC * DT_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[DT_KC * DT_LD];
+                                                         long long kper, double* __restrict__ C, double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) double As[DT_KC * DT_LD];
+  __shared__ __attribute__((aligned(16))) double Bs[DT_KC * DT_LD];
   __shared__ double red[3 * DT_B * DT_B];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane >> 3, lj = lane & 7;
   const int tiles_n = (n + DT_B - 1) / DT_B;
@@ -270,33 +274,39 @@ __global__ __launch_bounds__(256) void dot_nt_f64_kernel(const float* __restrict
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  // loader: quad q = tid + j * 256 -> (row = q >> 4, k = 4 * (q & 15))
-  auto stage = [&](const float* __restrict__ X, long long ldx, int rows, int r0, float* __restrict__ Xs, long long k0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = tid + j * 256, row = q >> 4, kq = 4 * (q & 15);
-      const long long k = k0 + kq;
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-      if (r0 + row < rows && k < ke) {
-        const float* src = X + (long long)(r0 + row) * ldx + k;
-        if (k + 3 < ke) { const f4u v = *reinterpret_cast<const f4u*>(src); v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3]; }
-        else { v0 = src[0]; if (k + 1 < ke) v1 = src[1]; if (k + 2 < ke) v2 = src[2]; }
-      }
-      Xs[(kq + 0) * DT_LD + row] = v0; Xs[(kq + 1) * DT_LD + row] = v1;
-      Xs[(kq + 2) * DT_LD + row] = v2; Xs[(kq + 3) * DT_LD + row] = v3;
+  // loader: quad tid -> (row = tid >> 3, k = 4 * (tid & 7)): one dword-aligned 16-byte load per operand and chunk
+  const int lrow = tid >> 3, lkq = 4 * (tid & 7);
+  const bool arow = m0 + lrow < m, brow = n0 + lrow < n;
+  const float* ap = A + (long long)(arow ? m0 + lrow : 0) * lda + lkq;
+  const float* bp = B + (long long)(brow ? n0 + lrow : 0) * ldb + lkq;
+  auto fetch = [&](const float* __restrict__ src, bool rowok, long long k0, float (&v)[4]) {
+    const long long k = k0 + lkq;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (rowok && k < ke) {
+      if (k + 3 < ke) { const f4u t = *reinterpret_cast<const f4u*>(src + k0); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+      else { v[0] = src[k0]; if (k + 1 < ke) v[1] = src[k0 + 1]; if (k + 2 < ke) v[2] = src[k0 + 2]; }
     }
   };
+  float ra[4], rb[4];
+  fetch(ap, arow, kb, ra);
+  fetch(bp, brow, kb, rb);
   for (long long k0 = kb; k0 < ke; k0 += DT_KC) {
-    stage(A, lda, m, m0, As, k0);
-    stage(B, ldb, n, n0, Bs, k0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      As[(lkq + t) * DT_LD + lrow] = (double)ra[t];
+      Bs[(lkq + t) * DT_LD + lrow] = (double)rb[t];
+    }
     __syncthreads();
-#pragma unroll 4
+    if (k0 + DT_KC < ke) { fetch(ap, arow, k0 + DT_KC, ra); fetch(bp, brow, k0 + DT_KC, rb); }
+#pragma unroll
     for (int kk = 0; kk < DT_KC / 4; ++kk) {
       const int k = wave * (DT_KC / 4) + kk;
-      const float4 a = *reinterpret_cast<const float4*>(&As[k * DT_LD + 4 * li]);
-      const float4 b = *reinterpret_cast<const float4*>(&Bs[k * DT_LD + 4 * lj]);
-      const double ad[4] = {(double)a.x, (double)a.y, (double)a.z, (double)a.w};
-      const double bd[4] = {(double)b.x, (double)b.y, (double)b.z, (double)b.w};
+      const double2 a0 = *reinterpret_cast<const double2*>(&As[k * DT_LD + 4 * li]);
+      const double2 a1 = *reinterpret_cast<const double2*>(&As[k * DT_LD + 4 * li + 2]);
+      const double2 b0 = *reinterpret_cast<const double2*>(&Bs[k * DT_LD + 4 * lj]);
+      const double2 b1 = *reinterpret_cast<const double2*>(&Bs[k * DT_LD + 4 * lj + 2]);
+      const double ad[4] = {a0.x, a0.y, a1.x, a1.y};
+      const double bd[4] = {b0.x, b0.y, b1.x, b1.y};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -312,6 +322,7 @@ __global__ __launch_bounds__(256) void dot_nt_f64_kernel(const float* __restrict
   }
   __syncthreads();
   if (wave == 0) {
+    double* mine = part ? part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (DT_B * DT_B) : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -319,9 +330,38 @@ __global__ __launch_bounds__(256) void dot_nt_f64_kernel(const float* __restrict
         const int e = (4 * li + i) * DT_B + 4 * lj + j;
         const double v = acc[i][j] + red[e] + red[DT_B * DT_B + e] + red[2 * DT_B * DT_B + e];
         const int r = m0 + 4 * li + i, c = n0 + 4 * lj + j;
-        if (r < m && c < n) unsafeAtomicAdd(C + (long long)r * n + c, v);
+        if (mine) mine[e] = v;
+        else if (r < m && c < n) unsafeAtomicAdd(C + (long long)r * n + c, v);
       }
   }
+}
+
+// second stage: C[r][c] = sum over the K-ranges of the partial tiles.  One block per 64 elements of a tile, sixteen
+// waves each summing every sixteenth partial (coalesced 512-byte reads), LDS for the last step — a serial loop over
+// hundreds of partials per thread would be latency-bound (measured: 190 us for 768 partials of one tile).
+__global__ __launch_bounds__(1024) void dot_nt_reduce_kernel(const double* __restrict__ part, int tiles, int ks, int m, int n,
+                                                             double* __restrict__ C) {
+  __shared__ double sm[16][64];
+  const int tile = blockIdx.x >> 4, e = ((blockIdx.x & 15) << 6) + (threadIdx.x & 63), ys = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int y = ys; y < ks; y += 16) s += part[((long long)y * tiles + tile) * (DT_B * DT_B) + e];
+  sm[ys][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ys == 0) {
+#pragma unroll
+    for (int y = 1; y < 16; ++y) s += sm[y][threadIdx.x];
+    const int tiles_n = (n + DT_B - 1) / DT_B;
+    const int r = (tile / tiles_n) * DT_B + e / DT_B, c = (tile % tiles_n) * DT_B + e % DT_B;
+    if (r < m && c < n) C[(long long)r * n + c] = s;
+  }
+}
+
+static double* dot_nt_scratch() {
+  static double* bufs[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!bufs[dev] && hipMalloc((void**)&bufs[dev], sizeof(double) * DT_SCRATCH_TILES * DT_B * DT_B) != hipSuccess) bufs[dev] = nullptr;
+  return bufs[dev];
 }
 
 // ---- Out[i] = zscale * Z[i] + sum_j Cm[i][j] Y[j]: r combinations of the s rows of Y (s, N), streamed once per tile of
@@ -393,6 +433,7 @@ __device__ __forceinline__ void philox4x32(unsigned long long ctr, unsigned long
 template <bool NORMAL>
 __global__ __launch_bounds__(KT) void fill_kernel(float* X, long long total, unsigned long long seed) {
   const long long nq = (total + 3) >> 2;
+  const bool aligned = (((unsigned long long)X) & 15ull) == 0;     // a slice of a block may start anywhere
   for (long long q = (long long)blockIdx.x * KT + threadIdx.x; q < nq; q += (long long)gridDim.x * KT) {
     unsigned int u[4];
     philox4x32((unsigned long long)q, seed, u);
@@ -412,10 +453,40 @@ __global__ __launch_bounds__(KT) void fill_kernel(float* X, long long total, uns
 #pragma unroll
       for (int h = 0; h < 4; ++h) v[h] = (u[h] & 0x80000000u) ? 1.f : -1.f;
     }
+    if (aligned && 4 * q + 3 < total) {
+      ST4(X, 4 * q, make_float4(v[0], v[1], v[2], v[3]));
+    } else {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const long long o = 4 * q + h;
-      if (o < total) X[o] = v[h];
+      for (int h = 0; h < 4; ++h) {
+        const long long o = 4 * q + h;
+        if (o < total) X[o] = v[h];
+      }
+    }
+  }
+}
+
+// Rademacher fill, one BIT per element: a Philox4x32-10 call is ~80 integer multiplies (v_mul_hi/lo at quarter rate),
+// which bounds a fill that spends one call per 16 bytes at ~4 TB/s — measured 3.4.  One call yields 128 sign bits = 128
+// elements = 512 bytes: thread t of a block writes the float4 at quad (chunk * 32 + i) * KT + t for i < 32, bit group i
+// of its 128-bit word, so every store instruction of a wave is one contiguous kilobyte and the kernel is write-bound.
+__global__ __launch_bounds__(KT) void fill_rademacher_kernel(float* X, long long total, unsigned long long seed) {
+  const long long nq = (total + 3) >> 2;                               // quads
+  const bool aligned = (((unsigned long long)X) & 15ull) == 0;
+  const long long nchunk = (nq + 32ll * KT - 1) / (32ll * KT);
+  for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    unsigned int u[4];
+    philox4x32((unsigned long long)(ch * KT + threadIdx.x), seed, u);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const long long q = (ch * 32 + i) * KT + threadIdx.x;
+      if (q >= nq) break;
+      const unsigned bits = u[i >> 3] >> (4 * (i & 7));
+      float v[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) v[h] = (bits >> h) & 1u ? 1.f : -1.f;
+      if (aligned && 4 * q + 3 < total) ST4(X, 4 * q, make_float4(v[0], v[1], v[2], v[3]));
+      else
+        for (int h = 0; h < 4; ++h) if (4 * q + h < total) X[4 * q + h] = v[h];
     }
   }
 }
@@ -533,18 +604,25 @@ int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64
                    void* stream) {
   if (!A || !B || !C || m <= 0 || n <= 0 || K <= 0 || lda < K || ldb < K) { set_error("lip_dot_nt_f64: bad argument"); return LIP_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  LIP_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(double) * (size_t)m * n, st));
   const long long tiles = (long long)((m + DT_B - 1) / DT_B) * ((n + DT_B - 1) / DT_B);
-  // split K until the launch has ~2048 blocks, whole 64-chunks per block, at least 16 chunks each
-  long long chunks = (K + DT_KC - 1) / DT_KC, ks = (2048 + tiles - 1) / tiles;
-  if (ks > chunks / 16) ks = chunks / 16;
+  // split K until the launch has ~3 blocks per CU (LDS allows 3), whole 32-chunks per block, at least 8 chunks each
+  long long chunks = (K + DT_KC - 1) / DT_KC, ks = (768 + tiles - 1) / tiles;
+  if (ks > chunks / 8) ks = chunks / 8;
   if (ks < 1) ks = 1;
   if (ks > 65535) ks = 65535;
   const long long kper = (chunks + ks - 1) / ks * DT_KC;
   ks = (K + kper - 1) / kper;
+  // partial tiles through the per-device scratch buffer (one launch in flight per device at a time: the library is
+  // thread-compatible, not thread-safe), float64 atomics when a launch has more partial tiles than it holds
+  double* part = (ks > 1 && tiles * ks <= DT_SCRATCH_TILES) ? dot_nt_scratch() : nullptr;
+  if (!part) LIP_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(double) * (size_t)m * n, st));
   hipLaunchKernelGGL(dot_nt_f64_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
-                     (long long)ldb, n, (long long)K, kper, C);
+                     (long long)ldb, n, (long long)K, kper, C, part);
   LIP_CHECK_HIP(hipGetLastError());
+  if (part) {
+    hipLaunchKernelGGL(dot_nt_reduce_kernel, dim3((unsigned)(tiles * 16)), dim3(1024), 0, st, part, (int)tiles, (int)ks, m, n, C);
+    LIP_CHECK_HIP(hipGetLastError());
+  }
   return LIP_OK;
 }
 
@@ -570,7 +648,7 @@ int lip_rows_combine(const double* Cm, const float* Y, int64_t ldy, int32_t s, c
 int lip_fill_rademacher(float* X, int32_t P, int64_t N, uint64_t seed, void* stream) {
   if (!X || P <= 0 || N <= 0) { set_error("lip_fill_rademacher: bad argument"); return LIP_ERR_ARG; }
   const long long total = (long long)P * N;
-  hipLaunchKernelGGL((fill_kernel<false>), dim3(nblk_for(total, KT * 16, 8192)), dim3(KT), 0, (hipStream_t)stream, X, total,
+  hipLaunchKernelGGL(fill_rademacher_kernel, dim3(nblk_for(total, KT * 128, 16384)), dim3(KT), 0, (hipStream_t)stream, X, total,
                      (unsigned long long)seed);
   LIP_CHECK_HIP(hipGetLastError());
   return LIP_OK;

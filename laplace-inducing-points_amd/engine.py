@@ -518,7 +518,7 @@ class LinearizedNet:
     """
 
     def __init__(self, state, Z: torch.Tensor, model_type: Optional[str] = None, device=None,
-                 workspace_bytes: int = 8 << 30, max_chunk: int = 1024):
+                 workspace_bytes: int = 8 << 30, max_chunk: int = 1024, work: Optional[torch.Tensor] = None):
         net = getattr(state, "net", None)
         if net is None:
             raise TypeError("the HIP engine needs state.net (a NetSpec layer program); an opaque apply_fn cannot "
@@ -543,9 +543,17 @@ class LinearizedNet:
         self.prim = torch.zeros(cn.prim_floats, **f32)
         nin = self.n * net.tensors[0][0] * net.tensors[0][1] * net.tensors[0][2]
         self.prim[cn.input_off:cn.input_off + nin] = net.prepare_input(Z.detach().to(**f32)).reshape(-1)
-        chunk = int(max(1, min(max_chunk, workspace_bytes // (4 * cn.work_pp))))
+        if work is not None:
+            # a probe workspace shared with other engines on the same stream (ExampleChunkedGGN: the chunks of a large
+            # data set run one after the other, so one workspace serves them all)
+            if not (work.is_cuda and work.dtype == torch.float32 and work.is_contiguous()) or work.numel() < cn.work_pp:
+                raise ValueError("shared workspace must be a contiguous float32 device tensor of >= work_pp floats")
+            chunk = int(min(max_chunk, work.numel() // cn.work_pp))
+            self.work = work
+        else:
+            chunk = int(max(1, min(max_chunk, workspace_bytes // (4 * cn.work_pp))))
+            self.work = torch.empty(cn.work_pp * chunk, **f32)
         self.chunk = chunk
-        self.work = torch.empty(cn.work_pp * chunk, **f32)
         h = C.c_void_p()
         nv.check(self.lib.lip_engine_create(C.byref(h), cn.D, self.n, cn.K), "lip_engine_create")
         self.h = h

@@ -83,25 +83,37 @@ def _logvar(state):
 class ExampleChunkedGGN:
     """GGN block operator over a data set too large for one engine binding: the examples are split into chunks,
     each chunk gets its own engine (cached primal pass), and the per-chunk products are summed — the data sum of
-    ``src/ggn.py:144`` is associative, so this is the single-GPU twin of the multi-GPU shard (``dist.py``)."""
+    ``src/ggn.py:144`` is associative, so this is the single-GPU twin of the multi-GPU shard (``dist.py``).
+    The chunks run one after the other on one stream and share ONE probe workspace (``workspace_bytes``); only the
+    primal caches are per chunk."""
 
-    def __init__(self, state, Z, model_type, full_set_size=None, example_chunk=64, workspace_bytes=8 << 30):
-        self.engines = []
+    def __init__(self, state, Z, model_type, full_set_size=None, example_chunk=64, workspace_bytes=8 << 30,
+                 max_probes=1024):
+        from .engine import compile_net
         n = Z.shape[0]
-        for s in range(0, n, example_chunk):
-            self.engines.append(LinearizedNet(state, Z[s:s + example_chunk], model_type, workspace_bytes=workspace_bytes))
+        if model_type is not None:
+            state.net.model_type = model_type
+        sizes = sorted({min(example_chunk, n - s) for s in range(0, n, example_chunk)})
+        work_pp = max(compile_net(state.net, m, state.params).work_pp for m in sizes)
+        probes = int(max(1, min(max_probes, workspace_bytes // (4 * work_pp))))
+        dev = Z.device if Z.is_cuda else torch.device("cuda")
+        self.work = torch.empty(work_pp * probes, device=dev, dtype=torch.float32)
+        self.engines = [LinearizedNet(state, Z[s:s + example_chunk], model_type, device=dev, work=self.work, max_chunk=probes)
+                        for s in range(0, n, example_chunk)]
         N = full_set_size or n
         self.scale = N / n * (math.exp(-_logvar(state)) if model_type == "regressor" else 1.0)
         self.D = self.engines[0].D
         self.engine = self.engines[0]
+        self.n = n
 
     def __call__(self, V, alpha: float = 0.0):
         single = V.dim() == 1
         Vb = V[None] if single else V
         Vb = Vb.to(device=self.engines[0].device, dtype=torch.float32).contiguous()
         Y = self.engines[0].ggn_vp(Vb, self.scale, alpha)
+        tmp = torch.empty_like(Y) if len(self.engines) > 1 else None
         for eng in self.engines[1:]:
-            Y += eng.ggn_vp(Vb, self.scale, 0.0)
+            Y += eng.ggn_vp(Vb, self.scale, 0.0, out=tmp)
         return Y[0] if single else Y
 
     rows = __call__

@@ -149,7 +149,6 @@ def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Te
     for j in range(k):
         w = matvec(Q[:, j].contiguous()).contiguous()      # (P, N) copy of basis row j (N may be < ldq)
         _chk(w)
-        wn2 = bdot(w, w)
         nv.check(lib.lip_multi_dot(nv.ptr(Qbuf), nv.ptr(w), nv.ptr(c1), P, j + 1, k, N, ldq, st), "lip_multi_dot")
         nv.check(lib.lip_multi_axpy_norm(nv.ptr(Qbuf), nv.ptr(c1), nv.ptr(w), nv.ptr(nrm2), P, j + 1, k, N, ldq, st), "lip_multi_axpy_norm")
         nv.check(lib.lip_multi_dot(nv.ptr(Qbuf), nv.ptr(w), nv.ptr(c2), P, j + 1, k, N, ldq, st), "lip_multi_dot")
@@ -159,6 +158,9 @@ def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Te
         # which leaves f(T) e1 unchanged instead of producing 0/0.
         diag[:, j] = torch.where(alive, c1[:, j] + c2[:, j], torch.ones_like(nrm2))
         if j + 1 < k:
+            # ||A q_j||^2 without a pass over w: the basis is orthonormal, so it is the residual's norm plus the
+            # squares of the coefficients taken out (Pythagoras; only a 1e-10-relative breakdown threshold hangs on it)
+            wn2 = nrm2 + ((c1[:, :j + 1] + c2[:, :j + 1]) ** 2).sum(1)
             alive = alive & (nrm2 > (1e-10 * wn2).clamp_min(1e-36))
             off[:, j] = torch.where(alive, torch.sqrt(nrm2), torch.zeros_like(nrm2))
             safe = torch.where(alive, nrm2, torch.full_like(nrm2, float("inf")))
@@ -207,6 +209,42 @@ def funm_lanczos_sym(dense_funm: Callable, num_matvecs: int):
                                          nv.stream_ptr()), "lip_multi_axpy_norm")
         return out
 
+    return estimate
+
+
+def funm_lanczos_dense(dense_funm: Callable, num_matvecs: int):
+    """``estimate(A, B)`` ~= f(A) B[p] for the rows of B (S, d) and an EXPLICIT symmetric A (d, d), all float64 on the
+    device: the reference's small-space Lanczos (``src/sample.py:113-128`` runs matfree's ``funm_lanczos_sym`` on the
+    dense d x d matrix alpha I + beta W^T W, d = M K <= ~1000).  Same recurrence as :func:`lanczos_tridiag` — full
+    re-orthogonalisation (two Gram-Schmidt passes), breakdown guard — as batched torch algebra: at d ~ 500 the vectors
+    are three orders of magnitude shorter than what the streaming HIP kernels are built for, and the matrix spans nine
+    decades, so the recurrence runs in float64."""
+    def estimate(A, B):
+        S, d = B.shape
+        k = min(int(num_matvecs), d)
+        length = B.norm(dim=1)
+        Q = torch.zeros(S, k, d, device=B.device, dtype=B.dtype)
+        diag = torch.ones(S, k, device=B.device, dtype=B.dtype)
+        off = torch.zeros(S, max(k - 1, 0), device=B.device, dtype=B.dtype)
+        q = B / length.clamp_min(1e-300)[:, None]
+        alive = length > 0
+        for j in range(k):
+            Q[:, j] = q
+            w = q @ A
+            wn = w.norm(dim=1)
+            Qj = Q[:, :j + 1]
+            c1 = torch.einsum("skd,sd->sk", Qj, w)
+            w = w - torch.einsum("sk,skd->sd", c1, Qj)
+            c2 = torch.einsum("skd,sd->sk", Qj, w)
+            w = w - torch.einsum("sk,skd->sd", c2, Qj)
+            diag[:, j] = torch.where(alive, c1[:, j] + c2[:, j], torch.ones_like(wn))
+            if j + 1 < k:
+                nrm = w.norm(dim=1)
+                alive = alive & (nrm > 1e-13 * wn.clamp_min(1e-300))
+                off[:, j] = torch.where(alive, nrm, torch.zeros_like(nrm))
+                q = torch.where(alive[:, None], w / nrm.clamp_min(1e-300)[:, None], torch.zeros_like(w))
+        fT = dense_funm(tridiag_dense(diag, off))
+        return torch.einsum("sk,skd->sd", fT[:, :, 0] * length[:, None], Q)
     return estimate
 
 

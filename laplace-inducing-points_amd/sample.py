@@ -129,7 +129,8 @@ class _SamplerParts:
         self.clip_min, self.method = clip_min, method
         f = lambda x: 1.0 / torch.sqrt(x)
         if method == "lanczos":
-            self.funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(f, clip_min, floor=self.alpha), self.depth)   # :113-115
+            self.funm = krylov.funm_lanczos_dense(krylov.dense_funm_sym_eigh(f, clip_min, floor=self.alpha), self.depth)   # :113-115
+            self.A_d64, self.G_pinv64 = A64.contiguous(), G_pinv.contiguous()
         elif method == "eigh":
             # alpha I + beta G_psd shares G_psd's eigenvectors: f(A) from the decomposition already at hand
             keep = evp > 0
@@ -159,8 +160,8 @@ class _SamplerParts:
             raise ValueError("method must be 'lanczos' or 'eigh'")
 
     def f_small(self, U: torch.Tensor) -> torch.Tensor:
-        """f(alpha I + beta W^T W) applied to the rows of U (S, d) — the reference's small-space Lanczos (:117-128)."""
-        return self.funm(lambda X: X @ self.A_d, U.contiguous())
+        """f(alpha I + beta W^T W) applied to the rows of U (S, d) float64 — the reference's small-space Lanczos (:117-128)."""
+        return self.funm(self.A_d64, U)
 
     def _correction(self, V: torch.Tensor):
         """(T, B) with  A^(-1/2) V = alpha^(-1/2) V + T B  (T small and float32, B the (rows, D) factor it multiplies)."""
@@ -178,9 +179,10 @@ class _SamplerParts:
         if self.method == "eigh":
             X = (U.double() @ self.Mc64).float().contiguous()                              # :78-84 and :130-138 fused
         else:
-            x1 = self.f_small(U) @ self.G_pinv                                             # :130-138
-            x2 = U @ self.G_pinv                                                           # :78-84
-            X = (x1 - a * x2).contiguous()
+            Ud = U.double()                                 # the d x d algebra spans nine decades: float64
+            x1 = self.f_small(Ud) @ self.G_pinv64                                          # :130-138
+            x2 = Ud @ self.G_pinv64                                                        # :78-84
+            X = (x1 - a * x2).float().contiguous()
         return X, self.Wm
 
     def apply(self, V: torch.Tensor) -> torch.Tensor:

@@ -43,8 +43,15 @@ def run(D=1084586, P=256, k=36):
             nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(nrm), nv.ptr(Q), min(j + 1, k - 1), Pl, k, D, ldq, st))
         t = timeit(lz, 10)
         bytes_ = 4 * D * Pl * (2 * ((j + 2) + (j + 3)) + 2)
-        res[f"j={j}"] = dict(ms=t*1e3, GBps=bytes_/t/1e9)
+        res[f"j={j}"] = dict(ms=t*1e3, GBps=bytes_/t/1e9, GBps_survey_model=4 * D * Pl * (7 + 2 * j) / t / 1e9)
     out["lanczos_step_cgs2"] = res
+    del Q, w
+    # float64-accumulated tall-skinny products and the streaming row combination (Hutch++ orthonormalisation, s = 20)
+    s_ = 20
+    Yb = krylov.fill_normal(s_, D, 10); Cm = torch.randn(s_, s_, dtype=torch.float64, device="cuda")
+    t = timeit(lambda: krylov.dot_nt(Yb, Yb)); out["dot_nt_f64"] = dict(ms=t*1e3, GBps=4*D*s_/t/1e9, shape=f"({s_} x D)({s_} x D)^T")
+    Ob = torch.empty_like(Yb)
+    t = timeit(lambda: krylov.rows_combine(Cm, Yb, out=Ob)); out["rows_combine"] = dict(ms=t*1e3, GBps=8*D*s_/t/1e9, shape=f"({s_} x {s_})({s_} x D)")
     return out
 
 if __name__ == "__main__":
