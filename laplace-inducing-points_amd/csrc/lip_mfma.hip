@@ -1281,6 +1281,11 @@ hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
     if (p.N > 32) return run_igemm<2, 2, 1, 1>(p, P, st);
     return run_igemm<2, 1, 1, 1>(p, P, st);
   }
+  // experiment switches (A/B only): LIP_TILE=2 one-wave blocks (32 x 32 / 32 x 64 per block, no cross-wave barrier),
+  // LIP_TILE=3 one wave with two row tiles (64 x 32), LIP_TILE=4 two-wave 64-row blocks
+  if (tile_override() == 2 && p.N <= 64) return p.N > 32 ? run_igemm<1, 1, 1, 2>(p, P, st) : run_igemm<1, 1, 1, 1>(p, P, st);
+  if (tile_override() == 3 && p.N <= 32) return run_igemm<1, 1, 2, 1>(p, P, st);
+  if (tile_override() == 4 && p.N <= 32) return run_igemm<2, 1, 1, 1>(p, P, st);
   const bool small_m = p.R <= 64;
   const bool big_m = p.R >= 4096 && tile_override() == 1;    // LIP_TILE=1: 256-row tiles (A/B: 15% slower on MI355X, r2)
   if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);

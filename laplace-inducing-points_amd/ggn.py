@@ -33,25 +33,41 @@ def _leaves(tree):
         yield tree
 
 
-def get_engine(state, Z, model_type) -> LinearizedNet:
-    """One engine per (theta snapshot, Z snapshot, model_type); the factories of the reference
-    snapshot ``flat_params`` at factory time (``src/ggn.py:10,108``) — so does the cache key
-    (data pointers + in-place version counters)."""
-    key = (model_type, id(state.net), tuple(Z.shape), Z.data_ptr(), Z._version,
-           tuple((t.data_ptr(), t._version) for t in _leaves(state.params) if torch.is_tensor(t)),
-           tuple((t.data_ptr(), t._version) for t in _leaves(state.batch_stats) if torch.is_tensor(t)))
-    eng = _ENGINE_CACHE.get(key)
+def engine_key(state, Z, model_type):
+    """Cache key of a binding: the factories of the reference snapshot ``flat_params`` at factory time
+    (``src/ggn.py:10,108``) — so does the key (data pointers + in-place version counters)."""
+    return (model_type, id(state.net), tuple(Z.shape), Z.data_ptr(), Z._version,
+            tuple((t.data_ptr(), t._version) for t in _leaves(state.params) if torch.is_tensor(t)),
+            tuple((t.data_ptr(), t._version) for t in _leaves(state.batch_stats) if torch.is_tensor(t)))
+
+
+_EVICTION_HOOKS = []          # callables(key) run when a binding leaves the cache (the sampler drops its parts)
+
+
+def get_engine(state, Z, model_type, workspace_bytes: int = 8 << 30) -> LinearizedNet:
+    """One engine per (theta snapshot, Z snapshot, model_type).  The cache is LRU: a hit moves the binding to the
+    fresh end, so the inducing-point engine an evaluation loop returns to every batch survives the per-batch
+    prediction engines that pass through (``scale_experiments/evaluate.py:98-154``)."""
+    key = engine_key(state, Z, model_type)
+    eng = _ENGINE_CACHE.pop(key, None)
     if eng is None:
-        eng = LinearizedNet(state, Z, model_type)
-        if len(_ENGINE_CACHE) >= _ENGINE_CACHE_MAX:
-            _ENGINE_CACHE.pop(next(iter(_ENGINE_CACHE)))
-        _ENGINE_CACHE[key] = eng
+        eng = LinearizedNet(state, Z, model_type, workspace_bytes=workspace_bytes)
         eng._keepalive = (state.params, state.batch_stats, Z)   # keep the keyed storage alive
+        eng.cache_key = key
+        while len(_ENGINE_CACHE) >= _ENGINE_CACHE_MAX:
+            old = next(iter(_ENGINE_CACHE))
+            _ENGINE_CACHE.pop(old)
+            for hook in _EVICTION_HOOKS:
+                hook(old)
+    _ENGINE_CACHE[key] = eng                                    # (re-)insert at the fresh end
     return eng
 
 
 def clear_engine_cache():
-    _ENGINE_CACHE.clear()
+    for key in list(_ENGINE_CACHE):
+        _ENGINE_CACHE.pop(key)
+        for hook in _EVICTION_HOOKS:
+            hook(key)
 
 
 class BlockOperator:

@@ -104,7 +104,7 @@ def predict_lla_scalable(map_state, Xnew, Z, model_type, alpha, key=None, full_s
     key = key if key is not None else 123                                       # :136
     w_samples = sample(map_state, Z, D, alpha=alpha, key=key, model_type=model_type, num_samples=num_samples,
                        full_set_size=full_set_size, **sample_kw)
-    eng = get_engine(map_state, Xnew, model_type)
+    eng = get_engine(map_state, Xnew, model_type, workspace_bytes=4 << 30)      # a per-batch binding: capped workspace
     fmu = eng.outputs()                                                         # (B, C)
     dys = eng.jvp(w_samples, "raw")                                             # (S, B, C)
     return fmu[None] + dys

@@ -205,21 +205,31 @@ class _SamplerParts:
 
 
 _PARTS_CACHE = {}
+_PARTS_CACHE_MAX = 2
+
+
+def _drop_parts_of(engine_key):
+    """An evicted engine takes its sampler parts (the multi-GB factor, the Gram, f(A)) with it."""
+    for k in [k for k in _PARTS_CACHE if k[0] == engine_key]:
+        _PARTS_CACHE.pop(k)
 
 
 def _cached_parts(state, Z, D, alpha, model_type, full_set_size, clip_min, method):
     """One factor / Gram / f(A) build per (engine binding, alpha, N, clip, method): evaluation loops call
     ``predict_lla_scalable`` once per test batch with the same (state, Z) (``scale_experiments/evaluate.py:103``),
-    and the reference rebuilds everything each time (``src/lla.py:137``)."""
-    from .ggn import get_engine
-    eng = get_engine(state, Z, model_type)
-    key = (id(eng), float(alpha), full_set_size, clip_min, method)
-    parts = _PARTS_CACHE.get(key)
+    and the reference rebuilds everything each time (``src/lla.py:137``).  Keyed on the engine's cache key and LRU
+    like the engine cache; parts die with their engine."""
+    from . import ggn as _g
+    if _drop_parts_of not in _g._EVICTION_HOOKS:
+        _g._EVICTION_HOOKS.append(_drop_parts_of)
+    eng = _g.get_engine(state, Z, model_type)
+    key = (eng.cache_key, float(alpha), full_set_size, clip_min, method)
+    parts = _PARTS_CACHE.pop(key, None)
     if parts is None or parts.eng is not eng:
         parts = _SamplerParts(state, Z, D, alpha, model_type, full_set_size, clip_min, method)
-        if len(_PARTS_CACHE) >= 2:
+        while len(_PARTS_CACHE) >= _PARTS_CACHE_MAX:
             _PARTS_CACHE.pop(next(iter(_PARTS_CACHE)))
-        _PARTS_CACHE[key] = parts
+    _PARTS_CACHE[key] = parts
     return parts
 
 

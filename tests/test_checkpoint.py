@@ -60,3 +60,36 @@ def test_trainstate_checkpoint_roundtrip(tmp_path, which):
         load_checkpoint(tmp_path, "nope", target=src)
     with pytest.raises(ValueError):
         load_checkpoint(tmp_path, "map_xor", target=create_state(SimpleClassifier(8, 2, 2), 1))
+
+
+def test_chunked_array_wire_format(monkeypatch):
+    """Arrays above the chunk limit travel as {'__msgpack_chunked_array__', 'shape': {'0': d0, ...}, 'chunks': {...}}
+    (flax writes the shape tuple through its tuple-to-dict helper); a small limit exercises the path, and a
+    hand-built message with the dict-form shape — and one with the list form — both read back."""
+    import msgpack
+    import numpy as np
+    from lip_amd import checkpoint as ck
+    monkeypatch.setattr(ck, "_MAX_CHUNK", 64)
+    a = np.arange(60, dtype=np.float32).reshape(3, 4, 5)
+    enc = ck.msgpack_serialize({"w": a})
+    raw = msgpack.unpackb(enc, raw=False, strict_map_key=False, ext_hook=lambda c, d: msgpack.ExtType(c, d))
+    assert raw["w"]["__msgpack_chunked_array__"] is True and raw["w"]["shape"] == {"0": 3, "1": 4, "2": 5}
+    assert len(raw["w"]["chunks"]) == 4
+    back = ck.msgpack_restore(enc)
+    assert back["w"].shape == (3, 4, 5) and np.array_equal(back["w"], a)
+    # hand-built: two chunks, dict-form and list-form shapes
+    def nd(x):
+        return msgpack.ExtType(1, msgpack.packb((list(x.shape), x.dtype.name, x.tobytes()), use_bin_type=True))
+    flat = a.reshape(-1)
+    for shape in ({"0": 3, "1": 4, "2": 5}, [3, 4, 5]):
+        msg = msgpack.packb({"w": {"__msgpack_chunked_array__": True, "shape": shape,
+                                   "chunks": {"0": nd(flat[:32]), "1": nd(flat[32:])}}}, use_bin_type=True)
+        assert np.array_equal(ck.msgpack_restore(msg)["w"], a)
+
+
+def test_same_numel_wrong_layout_is_refused():
+    import numpy as np
+    from lip_amd import checkpoint as ck
+    with pytest.raises(ValueError):
+        ck._check_like({"k": np.zeros((3, 3, 4, 8), np.float32)}, {"k": np.zeros((3, 3, 8, 4), np.float32)}, "params")
+    ck._check_like({"s": np.zeros((), np.float32)}, {"s": np.zeros((1,), np.float32)}, "params")
