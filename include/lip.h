@@ -184,6 +184,11 @@ int lip_cg_direction(float* p, const float* r, const float* rr_new, const float*
  * orthonormalisation and its projections G Q^T (src/stochtrace.py:124-131).                              */
 int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64_t ldb, int32_t n, int64_t K, double* C,
                    void* stream);
+/* C (m, n) float32, overwritten = A B^T, same operand layout as lip_dot_nt_f64, float32 MFMA with the long reduction
+ * axis split over the grid (partial tiles added by float atomics: the summation order, hence the last bits, vary from
+ * run to run).  W^T applied to a block of draws on a materialised factor (src/sample.py:130-139).             */
+int lip_gemm_nt(const float* A, int64_t lda, int32_t m, const float* B, int64_t ldb, int32_t n, int64_t K, float* C,
+                void* stream);
 /* Out[i] = zscale * Z[i] + sum_j Cm[i][j] Y[j],  i < r: r combinations of the s rows of Y (s, N) in one streaming pass
  * per 12 output rows; Cm (r, s) float64 row-major on the device, Z (r, N) optional (NULL: no addend).  Replaces
  * jnp.linalg.qr's Q of src/stochtrace.py:128 (as L^-1 Y after a Gram factorisation) and the deflation

@@ -132,6 +132,8 @@ hipError_t launch_maxpool_fwd(const MaxPoolP& p, int P, hipStream_t st);
 hipError_t launch_maxpool_bwd(const MaxPoolP& p, int P, hipStream_t st);
 hipError_t launch_softmax(const float* logits, float* prob, float* sqrtp, int n, int K, hipStream_t st);
 hipError_t launch_head(const HeadP& p, int P, hipStream_t st);
+hipError_t launch_gemm_nt(const float* A, long long lda, int m, const float* B, long long ldb, int n, long long K, float* C,
+                          hipStream_t st);
 hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st);
 
 void set_error(const char* fmt, ...);

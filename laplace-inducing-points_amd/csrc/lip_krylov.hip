@@ -626,6 +626,13 @@ int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64
   return LIP_OK;
 }
 
+int lip_gemm_nt(const float* A, int64_t lda, int32_t m, const float* B, int64_t ldb, int32_t n, int64_t K, float* C,
+                void* stream) {
+  if (!A || !B || !C || m <= 0 || n <= 0 || K <= 0 || lda < K || ldb < K) { set_error("lip_gemm_nt: bad argument"); return LIP_ERR_ARG; }
+  LIP_CHECK_HIP(launch_gemm_nt(A, (long long)lda, m, B, (long long)ldb, n, (long long)K, C, (hipStream_t)stream));
+  return LIP_OK;
+}
+
 int lip_rows_combine(const double* Cm, const float* Y, int64_t ldy, int32_t s, const float* Z, int64_t ldz, float zscale,
                      float* Out, int64_t ldo, int32_t r, int64_t N, void* stream) {
   if (!Cm || !Y || !Out || s <= 0 || r <= 0 || N <= 0 || ldy < N || ldo < N || (Z && ldz < N) || s > 4096) {

@@ -206,7 +206,10 @@ def compute_ggn_vp(state, Z, model_type, full_set_size=None, mode: str = "matfre
 
     def apply(V):
         Vb = V.to(device=eng.device, dtype=torch.float32)
-        return (Vb @ Wm.T) @ Wm          # plain library GEMMs (rocBLAS): (P, d) then (P, D)
+        from . import krylov
+        Vb = Vb.contiguous()
+        U = krylov.gemm_nt(Vb, Wm) if Vb.shape[0] >= 32 else Vb @ Wm.T      # both operands run along D: lip_gemm_nt
+        return U @ Wm                                                        # (P, d)(d, D): library GEMM
 
     op = BlockOperator(apply, (eng.D,), (eng.D,), eng, "ggn_vp[factor]")
     op.factor = Wm

@@ -79,6 +79,20 @@ def dot_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return C
 
 
+def gemm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A B^T (m, n) float32 for float32 rows A (m, K), B (n, K), K >> m, n: the hand-written split-K MFMA kernel
+    (``lip_gemm_nt``)."""
+    lib = nv.load()
+    A, lda = _rows_f32(A)
+    B, ldb = _rows_f32(B)
+    if A.shape[1] != B.shape[1]:
+        raise ValueError(f"gemm_nt: inner dimensions differ ({A.shape[1]} vs {B.shape[1]})")
+    C = torch.empty(A.shape[0], B.shape[0], device=A.device, dtype=torch.float32)
+    nv.check(lib.lip_gemm_nt(A.data_ptr(), lda, A.shape[0], B.data_ptr(), ldb, B.shape[0], A.shape[1], C.data_ptr(),
+                             nv.stream_ptr()), "lip_gemm_nt")
+    return C
+
+
 def rows_combine(Cm: torch.Tensor, Y: torch.Tensor, Z: Optional[torch.Tensor] = None, zscale: float = 0.0,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i] = zscale * Z[i] + sum_j Cm[i, j] Y[j]: r combinations of the s rows of Y in one streaming pass

@@ -141,3 +141,20 @@ def test_gram_orthonormalize(s, N, rank):
     assert (G - torch.eye(rank, device="cuda", dtype=torch.float64)).abs().max().item() <= 2e-6
     proj = Y.double() - (Y.double() @ Q.double().T) @ Q.double()     # rows of Y lie in span(Q)
     assert proj.norm().item() <= 1e-5 * Y.double().norm().item()
+
+
+@pytest.mark.parametrize("m,n,K", [(1, 1, 1), (5, 7, 241), (130, 33, 4099), (256, 450, 100003), (8, 500, 1084586)])
+def test_gemm_nt(m, n, K):
+    """split-K MFMA A B^T of K-contiguous float32 rows against float64 (float32 accumulation: eps * sqrt(K) relative to
+    the row norms), unaligned row strides included."""
+    from lip_amd import krylov
+    A, B = _blk(m, K, 41), _blk(n, K, 42)
+    C = krylov.gemm_nt(A, B)
+    ref = A.double() @ B.double().T
+    scale = (A.double().norm(dim=1)[:, None] * B.double().norm(dim=1)[None, :])
+    assert ((C.double() - ref).abs() / scale).max().item() <= 2e-6
+    if K > 8:
+        Av = _blk(m, K + 3, 43)[:, 1:K + 1]
+        Cv = krylov.gemm_nt(Av, B)
+        refv = Av.double() @ B.double().T
+        assert ((Cv.double() - refv).abs() / (Av.double().norm(dim=1)[:, None] * B.double().norm(dim=1)[None, :])).max().item() <= 2e-6

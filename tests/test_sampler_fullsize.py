@@ -83,7 +83,8 @@ def test_eigh_sampler_against_matrix_free_operator(setup):
     print("SAMPLER_FULLSIZE eigh " + json.dumps(m))
     eps = 2.0 ** -24
     assert m["eigpair_residual"] <= 2e-4
-    assert m["stiff_direction_error"] <= 2e-2
+    # floor: eps * sqrt(cond) = 3.3e-3 of a unit coefficient; coefficients down to 0.1 units are in the maximum
+    assert m["stiff_direction_error"] <= 5e-2
     # whitening: float32 factor rows and two float32 GEMM passes over D = 1.08 M; A^(1/2)-weighted error per draw is
     # ~ eps * sqrt(cond * d / D) ~ 6e-8 * sqrt(1e9 * 5e-4) ~ 4e-5 per rounding; a few dozen roundings accumulate
     assert m["whitening"] <= 3e-4
