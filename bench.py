@@ -80,7 +80,16 @@ def cpu_baseline(net, n, seconds_budget=12.0):
             torch.set_num_threads(all_threads)
     best_nt = max(by_threads, key=by_threads.get)
     bat = by_threads[best_nt]
+    # posterior samples/s of the reference's algorithm on these cores, from a bounded sample: src/sample.py:55-156 costs
+    # d x (one W sweep + one W^T sweep) for the Gram (src/ggn.py:207-219) and 2 W + 2 W^T sweeps per draw; a W^T sweep is
+    # the forward half and a W sweep the reverse half of one example-batched GGN-vp, so a (W, W^T) pair costs one
+    # product: seconds(S draws) = (d + 2 S) / rate  (the d x d Lanczos / solves are negligible next to that)
+    d_small, S_ref = n * 10, 200
+    cpu_samples = S_ref / ((d_small + 2 * S_ref) / max(lit, bat))
     return dict(value=max(lit, bat), unit="GGN-vp/s", cores=best_nt if bat >= lit else all_threads, kind="port",
+                posterior_samples_per_s_extrapolated=cpu_samples,
+                posterior_samples_model=f"S / ((d + 2 S) / GGN-vp rate) at d = {d_small}, S = {S_ref}: Gram build d sweeps pairs + "
+                                        "2 pairs per draw, small-space algebra not counted",
                 literal_per_example=lit, example_batched=bat,
                 example_batched_by_threads={str(k): v for k, v in by_threads.items()}, host_threads=all_threads,
                 sample=f"CPU restatement in PyTorch fp32 (not reference JAX): (a) literal per-example loop at {lit_nt} "
@@ -345,7 +354,25 @@ def main():
                                 "(the matrix-free kernel is), reported because it is what an inducing-point user "
                                 "should call")
 
-    # ---- Krylov / trace primitives: HBM roofline (algorithmic bytes / time, peak 8 TB/s spec) ------------------
+    # ---- few-probe call shape (the reference applies the operator to one vector at a time): direct launches vs the
+    # captured HIP graph of the same launch sequence ------------------------------------------------------------
+    single_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        single_line = {}
+        for Ps in (1, 8):
+            Vs = V[:Ps].contiguous()
+            for name, fn in (("direct", lambda: eng.ggn_vp(Vs, scale, alpha)), ("graph", lambda: eng.ggn_vp_graph(Vs, scale, alpha))):
+                fn(); fn()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    fn()
+                torch.cuda.synchronize()
+                single_line[f"P={Ps} {name}"] = dict(ms_per_product_block=1e3 * (time.perf_counter() - t1) / 50,
+                                                    ggn_vp_per_s=Ps * 50 / (time.perf_counter() - t1))
+        single_line["note"] = ("one (GGN + alpha I) v over the 50-example set per call, as a single-right-hand-side CG / Lanczos "
+                               "issues it: ~65 short launches; 'graph' replays them from a captured HIP graph (engine.ggn_vp_graph)")
+
     # ---- BASELINE configs[4] slice: full-resolution ResNet-50 (25.6 M parameters, K = 1000), 8 images x 64 probes ---
     r50_line = None
     if args.samples > 0 and not args.no_resnet50 and rank == 0 and world == 1:
@@ -401,7 +428,7 @@ def main():
         from lip_amd.sample import sample_lanczos
         st_l = state.to(device=dev, dtype=torch.float32)
         Zl = Z.to(dev)
-        S_l, k_l = 64, 36
+        S_l, k_l = 256, 36
         sample_lanczos(st_l, Zl, eng.D, alpha, 5, "classifier", num_samples=8, full_set_size=full, num_matvecs=4)   # warm-up
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -411,7 +438,8 @@ def main():
         lanczos_line = dict(value=S_l / t_l, unit="posterior samples/s", num_samples=S_l, num_matvecs=k_l, seconds=t_l,
                             matvec_share=k_l * (S_l / per_shard) / t_l, finite=bool(torch.isfinite(SL).all().item()),
                             note="(GGN + alpha I)^(-1/2) eps by k-step Lanczos with CGS2 re-orthogonalisation on the "
-                                 "matrix-free product (block of 64 recurrences); matvec_share = k * block sweep time at the "
+                                 "matrix-free product (block of 256 recurrences: the rate is bound by the products, headline / k = "
+                                 f"{per_shard / k_l:.0f} samples/s at most); matvec_share = k * block sweep time at the "
                                  "headline rate / total: the rest is the HBM-bound Krylov kernels and the small eigh")
         del SL
 
@@ -536,7 +564,7 @@ def main():
                                           "example_probe_products_per_s = value * examples_total is the figure that "
                                           "grows with N under weak scaling",
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, trace_estimators=trace_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, trace_estimators=trace_line, few_probes=single_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:

@@ -296,6 +296,34 @@ def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[
     return X, dict(iterations=it, residual_norm=torch.sqrt(rr))
 
 
+def cg_dense(A: torch.Tensor, B: torch.Tensor, tol: float = 1e-5, atol: float = 0.0, maxiter: Optional[int] = None):
+    """:func:`cg` for an EXPLICIT small symmetric matrix A (d, d) and right-hand sides B (P, d) in float64 on the
+    device — the small-space solves of the reference (``src/sample.py:71`` runs JAX's CG on the d x d Gram): same
+    stopping rule and defaults as :func:`cg`, plain torch algebra (d is ~1e1..1e3, and these Grams have condition
+    numbers far beyond what a float32 recurrence resolves)."""
+    A = A.double()
+    B = B.double()
+    P, d = B.shape
+    maxiter = 10 * d if maxiter is None else maxiter
+    X = torch.zeros_like(B)
+    R = B.clone()
+    Pd = R.clone()
+    rr = (R * R).sum(1)
+    atol2 = torch.clamp(tol * tol * (B * B).sum(1), min=atol * atol)
+    it = 0
+    while it < maxiter and bool((rr > atol2).any()):
+        act = rr > atol2
+        Ap = Pd @ A
+        a = torch.where(act, rr / (Pd * Ap).sum(1).clamp_min(1e-300), torch.zeros_like(rr))
+        X = X + a[:, None] * Pd
+        R = R - a[:, None] * Ap
+        rr_new = torch.where(act, (R * R).sum(1), rr)
+        Pd = torch.where(act[:, None], R + (rr_new / rr.clamp_min(1e-300))[:, None] * Pd, Pd)
+        rr = rr_new
+        it += 1
+    return X, dict(iterations=it, residual_norm=torch.sqrt(rr))
+
+
 def _basis(P: int, k: int, N: int, dev):
     ldq = (N + 3) // 4 * 4
     return torch.empty(P, k, ldq, device=dev, dtype=torch.float32), ldq

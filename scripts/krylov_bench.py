@@ -1,6 +1,6 @@
 """HBM roofline of the Krylov / trace primitives at the CIFAR config (D = 1 084 586): algorithmic bytes / time."""
 import sys, time, json, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lip_amd
 from lip_amd import krylov, _native as nv
 

@@ -18,7 +18,10 @@ src, tag = sys.argv[1], sys.argv[2]
 
 
 def counters(sub):
-    f = sorted(glob.glob(f"{src}/{sub}/**/*_counter_collection.csv", recursive=True))[0]
+    found = sorted(glob.glob(f"{src}/{sub}/**/*_counter_collection.csv", recursive=True))
+    if not found:                                   # optional pass (e.g. no SQ pass for the Krylov profile)
+        return collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0.0, 0]))
+    f = found[0]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0.0, 0]))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -44,12 +47,12 @@ for k in fetch:
     traffic[k] = dict(launches=n, avg_launch_ms=1e3 * f[1] / n, hbm_read_bytes_per_launch=rd,
                       hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
                       hbm_tb_per_s=(rd + wr) / (f[1] / n) / 1e12, l2_hit_rate=h / max(h + m, 1.0))
-json.dump(dict(command="rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum  "
-                       "-- python bench.py --steps 5 --warmup 2 --samples 0 --no-cpu-baseline",
+what = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 5 --warmup 2 --samples 0 --no-cpu-baseline"
+json.dump(dict(command="rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum  -- " + what,
                correction="read bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B); KiB -> bytes",
                kernels=traffic), open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 sqo = {}
-for k in sq:
+for k in (sq if sq else {}):
     if "lip::" not in k:
         continue
     d = {c: v[0] for c, v in sq[k].items()}
@@ -57,7 +60,8 @@ for k in sq:
     d["total_seconds"] = t
     d["mfma_busy_fraction_at_2p4GHz"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (t * 2.4e9 * 1024)
     sqo[k] = d
-json.dump(sqo, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
+if sqo:
+    json.dump(sqo, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
 for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["avg_launch_ms"] * kv[1]["launches"])[:8]:
     print(f"{k[:52]:52s} n={v['launches']:4d} {v['avg_launch_ms']:.2f} ms  {v['hbm_bytes_per_launch']/1e9:.2f} GB/launch "
           f"{v['hbm_tb_per_s']:.2f} TB/s  L2 hit {v['l2_hit_rate']:.2f}  mfma busy {sqo.get(k, {}).get('mfma_busy_fraction_at_2p4GHz', 0):.2f}")
