@@ -354,24 +354,25 @@ def main():
                                 "(the matrix-free kernel is), reported because it is what an inducing-point user "
                                 "should call")
 
-    # ---- few-probe call shape (the reference applies the operator to one vector at a time): direct launches vs the
-    # captured HIP graph of the same launch sequence ------------------------------------------------------------
+    # ---- few-probe call shape (the reference applies the operator to one vector at a time) -------------------------
     single_line = None
     if args.samples > 0 and rank == 0 and world == 1:
         single_line = {}
         for Ps in (1, 8):
             Vs = V[:Ps].contiguous()
-            for name, fn in (("direct", lambda: eng.ggn_vp(Vs, scale, alpha)), ("graph", lambda: eng.ggn_vp_graph(Vs, scale, alpha))):
-                fn(); fn()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(50):
-                    fn()
-                torch.cuda.synchronize()
-                single_line[f"P={Ps} {name}"] = dict(ms_per_product_block=1e3 * (time.perf_counter() - t1) / 50,
-                                                    ggn_vp_per_s=Ps * 50 / (time.perf_counter() - t1))
+            fn = lambda: eng.ggn_vp(Vs, scale, alpha)
+            fn(); fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            single_line[f"P={Ps}"] = dict(ms_per_product_block=1e3 * dt1 / 50, ggn_vp_per_s=Ps * 50 / dt1)
         single_line["note"] = ("one (GGN + alpha I) v over the 50-example set per call, as a single-right-hand-side CG / Lanczos "
-                               "issues it: ~65 short launches; 'graph' replays them from a captured HIP graph (engine.ggn_vp_graph)")
+                               "issues it: ~65 dependent launches of 20-60 us at less than one block per CU.  Replaying them "
+                               "from a captured HIP graph was measured at +-0 (2.29 vs 2.30 ms at P = 1): the product is bound "
+                               "by the kernels' own durations, not by their submission")
 
     # ---- BASELINE configs[4] slice: full-resolution ResNet-50 (25.6 M parameters, K = 1000), 8 images x 64 probes ---
     r50_line = None

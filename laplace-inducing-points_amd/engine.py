@@ -615,34 +615,6 @@ class LinearizedNet:
                                      nv.stream_ptr()), "lip_ggn_vp")
         return Y
 
-    def ggn_vp_graph(self, V: torch.Tensor, scale: float = 1.0, alpha: float = 0.0) -> torch.Tensor:
-        """:meth:`ggn_vp` replayed from a captured HIP graph — for the few-probe call shape (the reference applies the
-        operator to ONE vector at a time, ``src/ggn.py:133``; a single-right-hand-side CG / Lanczos does the same): a
-        product is ~65 short launches whose host-side submission costs as much as the kernels themselves at P = 1.
-        The launch sequence of one (P, scale, alpha) is captured once on the current stream into a graph with static
-        input / output blocks and replayed afterwards; the result is a view of the static output block (valid until
-        the next call with the same key).  The engine's launch path does no allocation, synchronisation or host copy,
-        which is what makes it capturable (include/lip.h)."""
-        Vb = self._block(V, self.D)
-        key = (int(Vb.shape[0]), float(scale), float(alpha))
-        graphs = self.__dict__.setdefault("_graphs", {})
-        ent = graphs.get(key)
-        if ent is None:
-            vin, out = torch.empty_like(Vb), torch.empty_like(Vb)
-            vin.copy_(Vb)
-            self.ggn_vp(vin, scale, alpha, out=out)              # warm-up outside the capture (lazy one-off allocations)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.ggn_vp(vin, scale, alpha, out=out)
-            ent = graphs[key] = (g, vin, out)
-            if len(graphs) > 8:
-                graphs.pop(next(iter(graphs)))
-        g, vin, out = ent
-        vin.copy_(Vb)
-        g.replay()
-        return out
-
     def jvp(self, V: torch.Tensor, mode: str = "raw", c: float = 1.0) -> torch.Tensor:
         Vb = self._block(V, self.D)
         U = torch.empty(Vb.shape[0], self.n, self.K, device=self.device, dtype=torch.float32)

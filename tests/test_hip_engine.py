@@ -199,24 +199,3 @@ def test_split_precision_mode_accuracy():
         set_precision("f32")
     assert e32 < 2e-6 and e16 < 5e-5, (e32, e16)
 
-
-def test_ggn_vp_graph_replay_matches_direct():
-    """The captured-graph replay of a single-vector product (the reference's call shape) is the same arithmetic."""
-    import lip_amd  # noqa: F401
-    from lip_amd.engine import LinearizedNet
-    from lip_amd.scalemodels import ResNet1M
-    from lip_amd.toymodels import create_state
-    net = ResNet1M(10, input_shape=(16, 16, 3), widths=(16, 32, 64), blocks_per_stage=1)
-    st = create_state(net, seed=0, dtype=torch.float32)
-    eng = LinearizedNet(st, torch.rand(6, 16, 16, 3).cuda(), "classifier", workspace_bytes=1 << 30, max_chunk=4)
-    for P in (1, 3):
-        V = torch.randn(P, eng.D, device="cuda")
-        ref = eng.ggn_vp(V, 7.0, 0.3).clone()
-        out1 = eng.ggn_vp_graph(V, 7.0, 0.3).clone()
-        V2 = torch.randn(P, eng.D, device="cuda")
-        ref2 = eng.ggn_vp(V2, 7.0, 0.3)
-        out2 = eng.ggn_vp_graph(V2, 7.0, 0.3)                      # replay with new data in the static input
-        torch.cuda.synchronize()
-        # atomics in the split weight-gradient reductions: summation order differs between launches
-        assert (out1 - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-        assert (out2 - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item()
