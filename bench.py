@@ -298,9 +298,10 @@ def main():
             tflops=s_flops / blk_s / 1e12, frac_of_f32_mfma_peak=s_flops / blk_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
             algorithmic_GBps=s_bytes / blk_s / 1e9, frac_of_hbm_peak=s_bytes / blk_s / 1e9 / 8000.0,
             bound="mfma (arithmetic intensity %.0f FLOP/B against a machine balance of 19.7)" % (s_flops / s_bytes),
-            kernels="the two (256 x r x D) passes are library GEMMs (hipBLASLt through torch.addmm); hand-written: the "
-                    "factor rows (lip_vjp_rows), the float64-accumulated stiff coefficients (lip_dot_nt_f64), the Philox "
-                    "normal fill",
+            kernels="pass 1 <q_k, eps> on lip_gemm_nt (split-K MFMA, both operands along D: 2.8 ms against hipBLASLt's "
+                    "6.4 ms), its stiffest rows again on lip_dot_nt_f64 (float64 accumulation), pass 2 eps a + T Qm as one "
+                    "library GEMM with the addend in its epilogue (hipBLASLt through torch.addmm, 107 TFLOP/s on that "
+                    "shape); factor rows from lip_vjp_rows, eps from the Philox normal fill",
             model="FLOPs 4 S r D + 2 S n_stiff D; bytes 4 D (2 r + 2 S) = two passes over the factor + read eps + write out")
         samples_line = dict(value=world * args.samples / ts, unit="posterior samples/s", num_samples=world * args.samples,
                             seconds=ts, at_2000_samples_same_binding=world * 2000 / ts2, ranks=world, roofline=samples_roofline,
@@ -512,6 +513,10 @@ def main():
         trace_line["hutchpp_v2_cifar_s1_20_s2_16"] = dict(
             seconds=t_h, trace=tr_h, products=56, products_seconds=t_mv, orthonormalisation_seconds=t_q,
             orthonormalisation_GBps=qr_bytes / t_q / 1e9, orthonormalisation_frac_of_hbm_peak=qr_bytes / t_q / 1e9 / 8000.0,
+            orthonormalisation_note="host-driven: 2 x (Gram kernel + s x s factorisation through rocSOLVER + combination "
+                                    "kernel); the two kernels alone are in `krylov` (dot_nt_f64: float64-FMA-bound at "
+                                    "s = 20 — gfx950's float64 peak equals 11 us for this Gram, the HBM time 15 us; "
+                                    "rows_combine: HBM-bound)",
             note="BASELINE configs[3]: hutchpp_v2 on GGN + alpha I over the 50 inducing images; the (D x 20) QR of "
                  "src/stochtrace.py:128 runs as a Gram orthonormalisation on lip_dot_nt_f64 + lip_rows_combine, twice: "
                  "bytes 2 x 12 D s (SURVEY 8d: >= 12 D s per pass); Hutchinson with 256 probes on the same binding is the "

@@ -118,9 +118,9 @@ def rows_combine(Cm: torch.Tensor, Y: torch.Tensor, Z: Optional[torch.Tensor] = 
 def gram_orthonormalize(Y: torch.Tensor, rtol: float = 1e-10, passes: int = 2) -> torch.Tensor:
     """Orthonormal rows spanning the rows of Y (s, N), N >> s, without a Householder QR of a tall matrix: the float64
     Gram G = Y Y^T (``dot_nt``: one read of Y), its s x s eigendecomposition G = U L U^T, Q = L^(-1/2) U^T Y
-    (``rows_combine``: one read + one write) — the CholeskyQR family with the symmetric factor L^(1/2) U^T in place of
-    the Cholesky factor, so a rank-deficient Y (Hutch++ with more probes than dimensions, ``tests/test_stochtrace.py:
-    90-97``) simply yields fewer rows.  Done twice ("CholeskyQR2"): the first pass leaves ||Q Q^T - I|| ~ eps cond(Y)^2,
+    (``rows_combine``: one read + one write) — CholeskyQR with the Cholesky factor where it exists and the symmetric
+    factor L^(1/2) U^T otherwise, so a rank-deficient Y (Hutch++ with more probes than dimensions,
+    ``tests/test_stochtrace.py:90-97``) simply yields fewer rows.  Done twice ("CholeskyQR2"): the first pass leaves ||Q Q^T - I|| ~ eps cond(Y)^2,
     the second brings it to rounding.  12 N s bytes per pass (>= 3 * 4 * D * s).  Replaces
     ``jnp.linalg.qr`` at ``src/stochtrace.py:128`` (only span(Q) enters the estimator)."""
     s_rows, N = Y.shape
@@ -131,9 +131,21 @@ def gram_orthonormalize(Y: torch.Tensor, rtol: float = 1e-10, passes: int = 2) -
     Q = Y
     for it in range(passes):
         G = dot_nt(Q, Q)
-        ev, U = torch.linalg.eigh(0.5 * (G + G.T))
-        keep = ev > (rtol if it == 0 else 0.25) * ev.max().clamp_min(1e-300)
-        Cm = (U[:, keep] * torch.rsqrt(ev[keep])).T
+        G = 0.5 * (G + G.T)
+        Cm = None
+        if s_rows <= 64:
+            # CholeskyQR proper: Q = L^-1 Y with G = L L^T (an s x s potrf + trtri is several times cheaper than the
+            # symmetric eigensolver at these sizes); a failed factorisation (rank-deficient or very ill-conditioned
+            # Y) falls through to the eigen-decomposition, which drops the null directions
+            L, info = torch.linalg.cholesky_ex(G)
+            if int(info.item()) == 0:
+                dg = L.diagonal()
+                if float(dg.min() / dg.max()) > (1e-5 if it == 0 else 0.25):
+                    Cm = torch.linalg.solve_triangular(L, torch.eye(Q.shape[0], device=G.device, dtype=G.dtype), upper=False)
+        if Cm is None:
+            ev, U = torch.linalg.eigh(G)
+            keep = ev > (rtol if it == 0 else 0.25) * ev.max().clamp_min(1e-300)
+            Cm = (U[:, keep] * torch.rsqrt(ev[keep])).T
         Q = rows_combine(Cm, Q)
     return Q
 
