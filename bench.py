@@ -423,6 +423,25 @@ def main():
             note="10k images x 1024 probes over 8 GPUs = 40 such 256-image sums x 64 probe blocks per GPU")
         del ch, V256, Y256, Z256
         torch.cuda.empty_cache()
+        # log-marginal-likelihood optimisation in alpha at this scale (configs[4]; src/train_alpha.py:13-59): two
+        # inducing images, d = 2 x 1000 — the factor (d x D x 4 B = 204 GB) is NOT materialised, the Gram comes
+        # matrix-free from d x (W then W^T) sweeps; 100 Adam steps on log alpha reuse its spectrum
+        from lip_amd.train_alpha import fit_alpha
+        st50d = st50.to(device=dev, dtype=torch.float32)
+        Zl = torch.rand(2, 224, 224, 3, generator=torch.Generator().manual_seed(6)).to(dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        a_fit, hist = fit_alpha(Zl, st50d, "classifier", full_set_size=10000, alpha0=1.0, alpha_lr=5e-2, steps=100)
+        torch.cuda.synchronize()
+        r50_line["lml_alpha_fit"] = dict(seconds=time.perf_counter() - t1, inducing_images=2, d=2000, steps=100,
+                                         alpha_start=hist[0][0], alpha_end=a_fit, lml_start=hist[0][1], lml_end=hist[-1][1],
+                                         increased=bool(hist[-1][1] > hist[0][1]),
+                                         note="Gram W^T W (2000 x 2000) assembled matrix-free: 2000 backward + 2000 tangent "
+                                              "sweeps over 2 images at 224 x 224, then O(d) per Adam step")
+        from lip_amd.ggn import clear_engine_cache
+        clear_engine_cache()
+        del Zl, st50d
+        torch.cuda.empty_cache()
 
     # ---- the north star's Krylov route: D-space Lanczos on the matrix-free GGN + alpha I (36 matvecs, full re-orth.) ----
     lanczos_line = None

@@ -289,7 +289,7 @@ def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
     if isinstance(W, BlockOperator) and W.engine is not None:
         dev = W.engine.device
         D = W.engine.D
-        bs = max(int(block), min(d, max(1, (1 << 30) // (4 * D))))
+        bs = max(int(block), min(d, max(1, (4 << 30) // (4 * D))))
         if d * D * 4 <= (8 << 30):
             Wm = torch.empty(d, D, device=dev, dtype=torch.float32)
             for s in range(0, d, bs):

@@ -75,3 +75,25 @@ def test_resnet50_224_operator_properties(r50):
     e_all = LinearizedNet(st, Zc, "classifier", work=work, max_chunk=2)
     Ya = e_all.ggn_vp(V, 10000.0 / 6.0, 0.25).double()
     assert (Yc - Ya).abs().max().item() <= 2e-5 * Ya.abs().max().item()
+
+
+def test_resnet50_224_log_marginal_likelihood_in_alpha(r50):
+    """configs[4]'s log-marginal-likelihood optimisation (``src/train_alpha.py:13-59``) at 224 x 224 with one inducing
+    image (d = K = 1000; the 102 GB factor is not materialised — the Gram is assembled matrix-free).  No dense object
+    exists to compare with at D = 25.6 M, so: the analytic d/d(log alpha) against a central difference of the value,
+    the Gram's spectrum is PSD with rank <= K - 1 = 999 (softmax: L sqrt(p) = 0), and Adam on log alpha ascends."""
+    from lip_amd.ggn import clear_engine_cache
+    from lip_amd.train_alpha import _lml_from_spectrum, _spectrum, fit_alpha
+    st, Z1 = r50["st32"], r50["Z"][:1].cuda().float()
+    lam, D, theta2 = _spectrum(Z1, st, "classifier")
+    assert D == 25557032 and lam.numel() == 1000
+    assert lam.min().item() >= 0.0 and (lam > 1e-5 * lam.max()).sum().item() <= 999
+    v0, g0 = _lml_from_spectrum(2.0, lam, D, theta2, 10000.0)
+    h = 1e-4
+    vp = _lml_from_spectrum(2.0 * (1 + h), lam, D, theta2, 10000.0)[0]
+    vm = _lml_from_spectrum(2.0 * (1 - h), lam, D, theta2, 10000.0)[0]
+    fd = (vp - vm) / (torch.log(torch.tensor((1 + h) / (1 - h), dtype=torch.float64)).item())
+    assert abs(fd - g0) <= 1e-5 * max(1.0, abs(g0))
+    a_fit, hist = fit_alpha(Z1, st, "classifier", full_set_size=10000, alpha0=1.0, steps=50)
+    assert hist[-1][1] > hist[0][1] and a_fit > 0
+    clear_engine_cache()
