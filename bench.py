@@ -273,11 +273,18 @@ def main():
         from lip_amd import sample as _smod
         _smod._PARTS_CACHE.clear()
         clear_engine_cache()
-        barrier()
+        import gc
+        gc.collect()                      # the warm-up binding's factor / Gram blocks go back to the allocator NOW, not at
+        barrier()                         # some later collection inside a timed region
         t1 = time.perf_counter()
         S = sample(st_dev, Zd, eng.D, alpha, 1392 + rank, "classifier", num_samples=args.samples, full_set_size=full)
         torch.cuda.synchronize()
         ts = time.perf_counter() - t1
+        # steady state on the bound sampler: one untimed pass first (its 8.7 GB result block may need a fresh hipMalloc,
+        # ~0.25 s, depending on what the caching allocator still holds), then the timed one
+        S = sample(st_dev, Zd, eng.D, alpha, 2392 + rank, "classifier", num_samples=2000, full_set_size=full)
+        del S
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         S = sample(st_dev, Zd, eng.D, alpha, 2393 + rank, "classifier", num_samples=2000, full_set_size=full)
         torch.cuda.synchronize()
