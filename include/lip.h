@@ -50,8 +50,11 @@ typedef struct {
 typedef struct {
   lip_ref_t a;
   lip_ref_t b;
-  int32_t IH, IW, C, KH, KW, stride, pad_h, pad_w, mode, reserved;
+  int32_t IH, IW, C, KH, KW, stride, pad_h, pad_w, mode;
+  int32_t flags;       /* LIP_SEG_B_TRANS: B is read as  B[(tap*C + c)][n] = b[(tap*N + n)*C + c]  — the HWIO kernel of the
+                          convolution being transposed, used in place (per-probe weight tangents have no transposed copy) */
 } lip_seg_t;
+#define LIP_SEG_B_TRANS 1
 
 enum {
   LIP_OP_IGEMM = 1,       /* implicit-GEMM conv / dense, fused epilogue (tangent fwd, data-grad, primal) */
@@ -137,6 +140,11 @@ int lip_engine_primal(lip_engine_t* e, void* stream);
 int lip_engine_profile(lip_engine_t* e, int32_t enable);
 int lip_engine_profile_read(lip_engine_t* e, double* ms_by_kind, int64_t* launches_by_kind, int32_t nkinds);
 
+/* run ONE host-supplied op on a single probe chunk (P <= chunk size) against the engine's bound buffers and the
+ * caller's V / Y / H blocks.  The second-order pass of the inducing-point gradient (reverse over the tangent tape,
+ * src/train_inducing.py:195-232) is driven from the host op by op through this entry point.                    */
+int lip_engine_run_op(lip_engine_t* e, const lip_op_t* op /*host*/, const float* V, float* Y, float* H, int32_t P,
+                      int32_t head_mode, float head_c, void* stream);
 /* test hook: run ops [first, first+count) of one tape on a single probe chunk (P <= chunk size) */
 int lip_debug_run_ops(lip_engine_t* e, int32_t which, int32_t first, int32_t count, const float* V, float* Y,
                       float* H, int32_t P, int32_t head_mode, float head_c, void* stream);

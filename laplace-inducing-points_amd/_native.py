@@ -19,6 +19,7 @@ OP_IGEMM, OP_WGRAD, OP_REDUCE, OP_POOL_FWD, OP_POOL_BWD, OP_PRIMAL_POST, OP_SOFT
 OP_MAXPOOL_PRIMAL, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD = 9, 10, 11
 HEAD_GGN, HEAD_LT, HEAD_L, HEAD_OUT, HEAD_IN = 0, 1, 2, 3, 4
 TAPE_PRIMAL, TAPE_TANGENT, TAPE_BACKWARD = 0, 1, 2
+SEG_B_TRANS = 1
 
 
 class Ref(C.Structure):
@@ -29,7 +30,7 @@ class Seg(C.Structure):
     _fields_ = [("a", Ref), ("b", Ref),
                 ("IH", C.c_int32), ("IW", C.c_int32), ("C", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
                 ("stride", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("mode", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class Op(C.Structure):
@@ -63,6 +64,7 @@ SIGNATURES = {
     "lip_engine_primal": (C.c_int, [_V, _V]),
     "lip_engine_profile": (C.c_int, [_V, C.c_int32]),
     "lip_engine_profile_read": (C.c_int, [_V, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+    "lip_engine_run_op": (C.c_int, [_V, C.POINTER(Op), _V, _V, _V, C.c_int32, C.c_int32, C.c_float, _V]),
     "lip_debug_run_ops": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, C.c_int32, C.c_int32,
                                     C.c_float, _V]),
     "lip_ggn_vp": (C.c_int, [_V, _V, _V, C.c_int32, C.c_float, C.c_float, _V]),

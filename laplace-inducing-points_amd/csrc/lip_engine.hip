@@ -118,6 +118,7 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
         q.IH = g.IH; q.IW = g.IW; q.C = g.C; q.KH = g.KH; q.KW = g.KW;
         q.stride = g.stride; q.pad_h = g.pad_h; q.pad_w = g.pad_w; q.mode = g.mode;
         q.Ktot = g.KH * g.KW * g.C;
+        q.b_trans = (g.flags & LIP_SEG_B_TRANS) ? 1 : 0;
         q.dC = FastDiv((unsigned)(g.C > 0 ? g.C : 1)); q.dKW = FastDiv((unsigned)(g.KW > 0 ? g.KW : 1));
         if (g.mode == 0) { q.mul = g.stride; q.sgn = 1; q.off_h = -g.pad_h; q.off_w = -g.pad_w; q.mask = 0; q.sh = 0; }
         else { q.mul = 1; q.sgn = -1; q.off_h = g.pad_h; q.off_w = g.pad_w; q.mask = g.stride - 1; q.sh = (g.stride == 2) ? 1 : 0; }
@@ -335,7 +336,7 @@ int ready(const lip_engine* e, const char* who) {
 
 extern "C" {
 
-int lip_abi_version(void) { return 4; }
+int lip_abi_version(void) { return 5; }
 const char* lip_last_error(void) { return g_err; }
 int lip_sizeof_op(void) { return (int)sizeof(lip_op_t); }
 int lip_set_precision(int32_t mode) { if (mode != 0 && mode != 1) { set_error("lip_set_precision: mode must be 0 (f32) or 1 (bf16x3)"); return LIP_ERR_ARG; } set_precision_mode(mode); return LIP_OK; }
@@ -409,6 +410,14 @@ int lip_engine_profile_read(lip_engine_t* e, double* ms_by_kind, int64_t* launch
   e->ev_used = 0;
   e->ev_kind.clear();
   return LIP_OK;
+}
+
+int lip_engine_run_op(lip_engine_t* e, const lip_op_t* op, const float* V, float* Y, float* H, int32_t P, int32_t head_mode,
+                      float head_c, void* stream) {
+  if (!e || !op || P <= 0 || P > e->max_chunk) { set_error("lip_engine_run_op: bad argument"); return LIP_ERR_ARG; }
+  if (!e->theta || !e->prim) { set_error("lip_engine_run_op: engine not bound"); return LIP_ERR_STATE; }
+  RunCtx c{e, V, Y, H, P, head_mode, head_c, (hipStream_t)stream};
+  return run_op(c, *op);
 }
 
 int lip_debug_run_ops(lip_engine_t* e, int32_t which, int32_t first, int32_t count, const float* V, float* Y,

@@ -30,6 +30,7 @@ struct SegP {
   const float* a; long long a_ps;
   const float* b; long long b_ps;
   int IH, IW, C, KH, KW, stride, pad_h, pad_w, mode, Ktot;
+  int b_trans;                          // LIP_SEG_B_TRANS (generic kernel only)
   FastDiv dC, dKW;
   // branch-free gather coordinate (fast kernel; stride in {1, 2}):
   //   t0 = o * mul + sgn * k + off ;  valid iff (t0 & mask) == 0 && 0 <= (t0 >> sh) < lim

@@ -414,7 +414,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
       const int e = tid + j * NT;
       const int k = e / BN, nn = e - k * BN;
       const int kg = k0 + k, col = n0 + nn;
-      breg[j] = (kg < s.Ktot && col < N) ? bbase[(unsigned)(kg * N + col)] : 0.f;
+      if (s.b_trans) {                    // B[(tap*C + c)][col] = b[(tap*N + col)*C + c]
+        const int tap = s.dC.div(kg), c = kg - tap * s.C;
+        breg[j] = (kg < s.Ktot && col < N) ? bbase[(unsigned)((tap * N + col) * s.C + c)] : 0.f;
+      } else {
+        breg[j] = (kg < s.Ktot && col < N) ? bbase[(unsigned)(kg * N + col)] : 0.f;
+      }
     }
   };
 
@@ -1288,7 +1293,7 @@ void set_precision_mode(int m) { g_precision = m ? 1 : 0; }
 static bool igemm_fast_ok(const IgemmP& p) {
   for (int s = 0; s < p.nseg; ++s) {
     const SegP& q = p.seg[s];
-    if ((q.C & 15) != 0 || (q.stride != 1 && q.stride != 2)) return false;
+    if ((q.C & 15) != 0 || (q.stride != 1 && q.stride != 2) || q.b_trans) return false;
     if ((((uintptr_t)q.a) & 15) || (q.a_ps & 3)) return false;
   }
   return true;

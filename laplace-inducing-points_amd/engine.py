@@ -71,6 +71,7 @@ class CompiledNet:
     const_plan: List[Tuple]           # how to fill the constants buffer
     prob_off: int
     input_off: int
+    meta: Dict[str, Any] = dataclasses.field(default_factory=dict)   # per-tensor offsets the second-order pass needs
 
 
 def _seg(a, b, IH, IW, Cc, KH, KW, stride, pad_h, pad_w, mode):
@@ -366,7 +367,9 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
     tapes = [[_lower(op) for op in tape] for tape in (primal, tangent, backward)]
     return CompiledNet(net=net, n=n, D=D, K=K, classifier=classifier, offsets=layout, prim_floats=max(prim, 4),
                        const_floats=cst, work_pp=work_pp, tapes=tapes, a_off=a_off, const_plan=const_plan,
-                       prob_off=prob_off, input_off=a_off[0])
+                       prob_off=prob_off, input_off=a_off[0],
+                       meta=dict(dphi_off=dphi_off, xhat_off=xhat_off, s_off=s_off, rstd_off=rstd_off, wt_off=wt_off,
+                                 sqrtp_off=sqrtp_off, layout=layout))
 
 
 def _has_grad(net: NetSpec, t: int) -> bool:
@@ -434,7 +437,7 @@ def _lower(op: SymOp) -> nv.Op:
             o.seg[i].a = _mkref(op, s["a"])
             o.seg[i].b = _mkref(op, s.get("b", NONE))
             for k, fld in (("IH", "IH"), ("IW", "IW"), ("C", "C"), ("KH", "KH"), ("KW", "KW"), ("stride", "stride"),
-                           ("pad_h", "pad_h"), ("pad_w", "pad_w"), ("mode", "mode")):
+                           ("pad_h", "pad_h"), ("pad_w", "pad_w"), ("mode", "mode"), ("flags", "flags")):
                 setattr(o.seg[i], fld, int(s.get(k, 0)))
         else:
             o.seg[i].a = _mkref(op, NONE)
@@ -614,6 +617,13 @@ class LinearizedNet:
         nv.check(self.lib.lip_ggn_vp(self.h, nv.ptr(Vb), nv.ptr(Y), Vb.shape[0], float(scale), float(alpha),
                                      nv.stream_ptr()), "lip_ggn_vp")
         return Y
+
+    def run_op(self, op: "nv.Op", P: int, V: Optional[torch.Tensor] = None, Y: Optional[torch.Tensor] = None,
+               H: Optional[torch.Tensor] = None, head_mode: int = 0, head_c: float = 1.0) -> None:
+        """Launch ONE host-built op against this binding (``lip_engine_run_op``): operands in the THETA / CONST / PRIM /
+        WORK spaces resolve to the engine's buffers, VIN / YOUT / HEAD to the blocks passed here."""
+        nv.check(self.lib.lip_engine_run_op(self.h, C.byref(op), nv.ptr(V), nv.ptr(Y), nv.ptr(H), int(P), int(head_mode),
+                                            float(head_c), nv.stream_ptr()), "lip_engine_run_op")
 
     def jvp(self, V: torch.Tensor, mode: str = "raw", c: float = 1.0) -> torch.Tensor:
         Vb = self._block(V, self.D)

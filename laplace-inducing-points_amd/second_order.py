@@ -1,0 +1,313 @@
+"""Second-order pass of the inducing-point gradient on the engine's kernels: the input derivative of the
+parameter-JVP pairing
+
+    phi(Z) = sum_{i, k} < J(z_i) m_{ik} , c L(z_i) e_k >,        grad_{z_i} phi
+
+(``jax.value_and_grad(alternative_objective_scalable)`` differentiates through it, ``src/train_inducing.py:195-232``;
+the directions m_ik = (Q W)_(i,k) are frozen, see ``train_inducing.py``).  It is reverse mode over the tangent tape:
+
+  forward   da_l = act'(y_l) dy_l,   dy_l = s (conv(da_{l-1}, W) + conv(a_{l-1}, dW_ik)) + dgamma_ik xhat_l + dbeta_ik + dres
+  reverse   given the adjoints DA_l (per probe) of da_l and A_l of a_l:
+            DY = act' DA ;  Y = act' A + sum_k act'' dy_k DA_k ;  residual branches take DY / Y
+            Z' = Y + sum_k (dgamma_ik / gamma) DY_k                      (BN: xhat depends on z)
+            DA_{l-1} += convT(s DY, W) ;  A_{l-1} += convT(s Z', W) + sum_k convT(s DY_k, dW_ik)
+
+The direction differs per EXAMPLE, so the segments with a weight tangent run one launch per example (``n_img = 1``,
+operand offsets shifted to example i); the shared-weight segments run over all examples at once.  Every convolution
+/ transposed convolution is an ``LIP_OP_IGEMM`` launched through ``lip_engine_run_op`` — the transposed ones read
+the HWIO kernel in place (``LIP_SEG_B_TRANS``: a weight tangent has no transposed copy) — the per-element glue between
+them (act', act'', BN factors, sums over the K probes) is torch algebra on the arena the ops read and write.
+
+Supported: the units of the reference's MLPs and ResNet1M (Dense / conv with bias or eval-mode BN, residual adds,
+ReLU / tanh / identity anywhere, GELU on Dense layers, global mean pool, flatten views); window pools (LeNet5, the
+ResNet-50 stem) are refused.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _native as nv
+from .netspec import _get
+
+
+class EngineExecutor:
+    """Runs host-built ops on a :class:`~lip_amd.engine.LinearizedNet` binding (float32, device)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.cn, self.device, self.dtype = eng.cn, eng.device, torch.float32
+        self.prim, self.consts, self.theta = eng.prim, eng.consts, eng.theta
+        self.max_probes = eng.chunk
+
+    def run(self, op, P, V, Y):
+        self.eng.run_op(op, P, V=V, Y=Y)
+
+
+def _ref(space, off=0, pstride=0):
+    return nv.Ref(int(space), 0, int(off), int(pstride))
+
+
+NONE = _ref(nv.SP_NONE)
+
+
+def _igemm(n_img, OH, OW, N, seg, out, res=None):
+    o = nv.Op()
+    o.kind, o.nseg = nv.OP_IGEMM, 1
+    for name in nv.REF_FIELDS:
+        setattr(o, name, NONE)
+    for i in range(3):
+        o.seg[i].a = NONE
+        o.seg[i].b = NONE
+    s = o.seg[0]
+    s.a, s.b = seg["a"], seg["b"]
+    for k in ("IH", "IW", "C", "KH", "KW", "stride", "pad_h", "pad_w", "mode", "flags"):
+        setattr(s, k, int(seg.get(k, 0)))
+    o.n_img, o.OH, o.OW, o.N = int(n_img), int(OH), int(OW), int(N)
+    o.out = out
+    if res is not None:
+        o.res = res
+    return o
+
+
+def _act2(name: str, a: torch.Tensor, dphi: Optional[torch.Tensor], y: Optional[torch.Tensor]):
+    """act''(y) from what the primal pass cached (a = act(y), dphi = act'(y)); None when it vanishes."""
+    if name in ("none", "relu"):
+        return None
+    if name == "tanh":
+        return -2.0 * a * dphi
+    if name == "gelu":
+        if y is None:
+            raise NotImplementedError("second-order pass: GELU is supported on Dense layers only")
+        c0 = math.sqrt(2.0 / math.pi)
+        u = c0 * (y + 0.044715 * y ** 3)
+        t = torch.tanh(u)
+        du = c0 * (1.0 + 3 * 0.044715 * y ** 2)
+        d2u = c0 * 6 * 0.044715 * y
+        sech2 = 1.0 - t * t
+        # phi = 0.5 y (1 + t):  phi' = 0.5 (1 + t) + 0.5 y sech2 du ;  phi'' = sech2 du + 0.5 y (sech2 d2u - 2 t sech2 du^2)
+        return sech2 * du + 0.5 * y * (sech2 * d2u - 2.0 * t * sech2 * du * du)
+    raise ValueError(name)
+
+
+def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str) -> torch.Tensor:
+    """grad_Z of  sum_{i,k} < J(z_i) Mdir[i, k] , c_out L(z_i) e_k >  for the binding behind ``ex``.
+
+    ``Mdir`` is (n, K, D) on the executor's device: direction k of example i.  Returns (n, *input_shape_raw)."""
+    cn = ex.cn
+    net, n, D, K = cn.net, cn.n, cn.D, cn.K
+    dev, dt = ex.device, ex.dtype
+    tens = net.tensors
+    meta = cn.meta
+    layout = meta["layout"]
+    if tuple(Mdir.shape) != (n, K, D):
+        raise ValueError(f"directions must be (n, K, D) = {(n, K, D)}, got {tuple(Mdir.shape)}")
+    if K > ex.max_probes:
+        raise NotImplementedError(f"second-order pass: K = {K} probes exceed the engine's chunk of {ex.max_probes}")
+    Mdir = Mdir.to(device=dev, dtype=dt).contiguous()
+    classifier = model_type == "classifier"
+
+    def size(t):
+        h, w, c = tens[t]
+        return h * w * c
+
+    def poff(path):
+        return layout[path][0]
+
+    def prim(off, count):
+        return ex.prim[off:off + count]
+
+    def pdir(path):
+        """(K, n, numel) view of the direction's slice for one parameter leaf."""
+        off, shape = layout[path]
+        cnt = math.prod(shape) if shape else 1
+        return Mdir[:, :, off:off + cnt].permute(1, 0, 2)
+
+    producer = {u.dst: u for u in net.units}
+    has_tan: Dict[int, bool] = {0: False}
+    for u in net.units:
+        has_tan[u.dst] = True if u.kind == "conv" else has_tan[u.src]
+
+    # ---------------------------------------------------------------- arena: every buffer the ops touch
+    alias: Dict[int, int] = {}
+    for u in net.units:
+        if u.kind == "view":
+            alias[u.dst] = alias.get(u.src, u.src)
+    root = lambda t: alias.get(t, t)
+    slots: Dict[str, int] = {}
+    top = 0
+
+    def alloc(name, count):
+        nonlocal top
+        slots[name] = top
+        top += (count + 3) // 4 * 4
+
+    maxsz = max(size(t) for t in range(len(tens)))
+    for t in range(len(tens)):
+        if root(t) != t:
+            continue
+        if has_tan.get(t, False):
+            alloc(f"T{t}", K * n * size(t))
+            alloc(f"DA{t}", K * n * size(t))
+        alloc(f"A{t}", n * size(t))
+    for nm, cnt in (("ACC", K * n * maxsz), ("SDY", K * n * maxsz), ("SZB", n * maxsz), ("TMP", K * n * maxsz)):
+        alloc(nm, cnt)
+    arena = torch.zeros(top, device=dev, dtype=dt)
+
+    def buf(name, *shape):
+        cnt = math.prod(shape)
+        return arena[slots[name]:slots[name] + cnt].view(*shape)
+
+    Y = lambda name, off=0, ps=0: _ref(nv.SP_YOUT, slots[name] + off, ps)
+    dys: Dict[int, torch.Tensor] = {}
+
+    def geom(u):
+        ih, iw, _ = tens[u.src]
+        return dict(IH=ih, IW=iw, C=u.cin, KH=u.kh, KW=u.kw, stride=u.stride, pad_h=u.pad_h, pad_w=u.pad_w, mode=0, flags=0)
+
+    def geom_t(u):
+        """transposed convolution of unit u: gathers the cotangent of u.dst, produces a tensor shaped like u.src"""
+        oh, ow, _ = tens[u.dst]
+        return dict(IH=oh, IW=ow, C=u.cout, KH=u.kh, KW=u.kw, stride=u.stride, pad_h=u.pad_h, pad_w=u.pad_w, mode=1,
+                    flags=nv.SEG_B_TRANS)
+
+    def bn_factors(u):
+        if u.bn_scale is None:
+            return None
+        so = meta["s_off"][u.dst]
+        s = ex.consts[so:so + u.cout]
+        gamma = ex.theta[poff(u.bn_scale):poff(u.bn_scale) + u.cout]
+        return s, gamma
+
+    def unit_primals(u):
+        """(a, dphi or None, act'' or None) of unit u's output, each (n, size) or None"""
+        sz = size(u.dst)
+        a = prim(cn.a_off[u.dst], n * sz).view(n, sz)
+        dphi = prim(meta["dphi_off"][u.dst], n * sz).view(n, sz) if u.dst in meta["dphi_off"] else None
+        y = None
+        if u.act == "gelu":
+            ih, iw, _ = tens[u.src]
+            if not (u.kh == ih and u.kw == iw and tens[u.dst][:2] == (1, 1) and u.bn_scale is None and u.res is None):
+                raise NotImplementedError("second-order pass: GELU is supported on Dense layers only")
+            a_src = prim(cn.a_off[u.src], n * size(u.src)).view(n, size(u.src))
+            W = ex.theta[poff(u.kernel):poff(u.kernel) + u.kh * u.kw * u.cin * u.cout].view(-1, u.cout)
+            y = a_src @ W
+            if u.bias is not None:
+                y = y + ex.theta[poff(u.bias):poff(u.bias) + u.cout]
+        return a, dphi, _act2(u.act, a, dphi, y)
+
+    # ---------------------------------------------------------------- forward: tangents of every tensor, kept
+    for u in net.units:
+        if u.kind == "view":
+            continue
+        src, dst = root(u.src), u.dst
+        if u.kind == "meanpool":
+            h, w, c = tens[u.src]
+            Ts = buf(f"T{src}", K, n, h * w, c)
+            buf(f"T{dst}", K, n, c).copy_(Ts.mean(2))
+            continue
+        if u.kind != "conv":
+            raise NotImplementedError(f"second-order pass: unit kind '{u.kind}' (window pools) is not supported")
+        oh, ow, co = tens[dst]
+        sz, ssz = size(dst), size(u.src)
+        acc = buf("ACC", K, n, sz)
+        shared = has_tan[u.src]
+        if shared:   # conv(da, W) over all examples
+            ex.run(_igemm(n, oh, ow, co, dict(geom(u), a=Y(f"T{src}", 0, n * ssz), b=_ref(nv.SP_THETA, poff(u.kernel))),
+                          Y("ACC", 0, n * sz)), K, Mdir, arena)
+        for i in range(n):   # + conv(a_i, dW_ik): the weight tangent is the example's own
+            seg = dict(geom(u), a=_ref(nv.SP_PRIM, cn.a_off[u.src] + i * ssz), b=_ref(nv.SP_VIN, i * K * D + poff(u.kernel), D))
+            o = Y("ACC", i * sz, n * sz)
+            ex.run(_igemm(1, oh, ow, co, seg, o, res=o if shared else None), K, Mdir, arena)
+        a, dphi, _ = unit_primals(u)
+        dy = acc.view(K, n, oh * ow, co)
+        bn = bn_factors(u)
+        if bn is not None:
+            s, gamma = bn
+            xhat = prim(meta["xhat_off"][dst], n * sz).view(1, n, oh * ow, co)
+            dy = dy * s + pdir(u.bn_scale).view(K, n, 1, co) * xhat + pdir(u.bn_bias).view(K, n, 1, co)
+        elif u.bias is not None:
+            dy = dy + pdir(u.bias).view(K, n, 1, co)
+        dy = dy.reshape(K, n, sz)
+        if u.res is not None and has_tan[u.res]:
+            dy = dy + buf(f"T{root(u.res)}", K, n, sz)
+        if u.act in ("tanh", "gelu"):
+            dys[dst] = dy.clone()
+        buf(f"T{dst}", K, n, sz).copy_(dy * dphi if dphi is not None else dy)
+
+    # ---------------------------------------------------------------- head: adjoints of the logits' tangent / value
+    out_t = root(net.out)
+    U = buf(f"T{out_t}", K, n, K).permute(1, 0, 2).double()           # U[i, k, a] = (J(z_i) m_ik)_a
+    if classifier:
+        p = prim(cn.prob_off, n * K).view(n, K).double()
+        s = torch.sqrt(p)
+        eye = torch.eye(K, device=dev, dtype=torch.float64)
+        ubar = c_out * s[:, :, None] * (eye[None] - p[:, None, :])     # [i, k, a] = c s_ik (delta_ak - p_ia) = c (L e_k)_a
+        d = torch.diagonal(U, dim1=1, dim2=2)                          # U[i, k, k]
+        w = (U * p[:, None, :]).sum(-1)                                # sum_a p_a U[i, k, a]
+        g = s * (d - w)                                                # s_k (d_k - w_k)
+        fbar = c_out * (0.5 * g - 0.5 * p * g.sum(-1, keepdim=True) - p * ((s[:, :, None] * (U - w[:, :, None])).sum(1)))
+    else:
+        ubar = torch.full((n, K, K), float(c_out), device=dev, dtype=torch.float64) * torch.eye(K, device=dev, dtype=torch.float64)
+        fbar = torch.zeros(n, K, device=dev, dtype=torch.float64)
+    buf(f"DA{out_t}", K, n, K).copy_(ubar.permute(1, 0, 2).to(dt))
+    buf(f"A{out_t}", n, K).copy_(fbar.to(dt))
+
+    # ---------------------------------------------------------------- reverse
+    for u in reversed(net.units):
+        if u.kind == "view":
+            continue
+        src, dst = root(u.src), u.dst
+        if u.kind == "meanpool":
+            h, w, c = tens[u.src]
+            if has_tan[u.src]:
+                buf(f"DA{src}", K, n, h * w, c).add_(buf(f"DA{dst}", K, n, 1, c) / (h * w))
+            buf(f"A{src}", n, h * w, c).add_(buf(f"A{dst}", n, 1, c) / (h * w))
+            continue
+        oh, ow, co = tens[dst]
+        sz, ssz = size(dst), size(u.src)
+        sh, sw, sc = tens[u.src]
+        a, dphi, ddphi = unit_primals(u)
+        DA, AB = buf(f"DA{dst}", K, n, sz), buf(f"A{dst}", n, sz)
+        DYb = DA * dphi if dphi is not None else DA
+        Yb = AB * dphi if dphi is not None else AB.clone()
+        if ddphi is not None:
+            Yb = Yb + (ddphi * dys[dst] * DA).sum(0)
+        if u.res is not None:
+            r = root(u.res)
+            if has_tan[u.res]:
+                buf(f"DA{r}", K, n, sz).add_(DYb)
+            buf(f"A{r}", n, sz).add_(Yb)
+        bn = bn_factors(u)
+        sdy, szb = buf("SDY", K, n, oh * ow, co), buf("SZB", n, oh * ow, co)
+        DYv, Ybv = DYb.reshape(K, n, oh * ow, co), Yb.reshape(n, oh * ow, co)
+        if bn is not None:
+            s, gamma = bn
+            ratio = pdir(u.bn_scale).view(K, n, 1, co) / gamma          # dgamma_ik / gamma
+            sdy.copy_(DYv * s)
+            szb.copy_((Ybv + (ratio * DYv).sum(0)) * s)
+        else:
+            sdy.copy_(DYv)
+            szb.copy_(Ybv)
+        tmp = buf("TMP", K, n, ssz)
+        wref = _ref(nv.SP_THETA, poff(u.kernel))
+        if has_tan[u.src]:   # DA_src += convT(s DY, W)
+            ex.run(_igemm(n, sh, sw, sc, dict(geom_t(u), a=Y("SDY", 0, n * sz), b=wref), Y("TMP", 0, n * ssz)), K, Mdir, arena)
+            buf(f"DA{src}", K, n, ssz).add_(tmp)
+        # A_src += convT(s Z', W)   (one "probe")
+        ex.run(_igemm(n, sh, sw, sc, dict(geom_t(u), a=Y("SZB", 0, 0), b=wref), Y("TMP", 0, 0)), 1, Mdir, arena)
+        buf(f"A{src}", n, ssz).add_(buf("TMP", n, ssz))
+        # A_src_i += sum_k convT(s DY_ik, dW_ik)
+        for i in range(n):
+            seg = dict(geom_t(u), a=Y("SDY", i * sz, n * sz), b=_ref(nv.SP_VIN, i * K * D + poff(u.kernel), D))
+            ex.run(_igemm(1, sh, sw, sc, seg, Y("TMP", i * ssz, n * ssz)), K, Mdir, arena)
+        buf(f"A{src}", n, ssz).add_(tmp.sum(0))
+
+    h0, w0, c0 = tens[0]
+    g = buf("A0", n, h0, w0, c0)
+    t = net.tile_channels
+    if t > 1:
+        g = g.reshape(n, h0, w0, t, c0 // t).sum(3)
+    return g.reshape((n,) + tuple(net.input_shape_raw)).clone()

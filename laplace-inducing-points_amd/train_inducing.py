@@ -3,8 +3,8 @@
 ``alternative_objective_dense`` (``:176-193``), ``alternative_objective_scalable_exact`` (``:26-84``) and
 ``alternative_objective_scalable`` (``:87-173``): KL[q(theta|Z) || q(theta|data)] up to constants =
 log-det term + trace term, and their gradients w.r.t. Z (``value_and_grad`` at ``:195-196``, ``optimize_step``
-``:199-232``): exact, with every D-sized quantity on the HIP engine and only the last, second-order step (the input
-derivative of a parameter-JVP) on ``torch.func`` — see the comment block above ``variational_grad_scalable``.
+``:199-232``): exact, with every D-sized quantity on the HIP engine, including the last, second-order step (the input
+derivative of a parameter-JVP: reverse mode over the tangent tape, ``second_order.py``).
 
 SURVEY §4.1-9: the reference's stochastic log-det omits beta (it bidiagonalises v -> [sqrt(alpha) v ; Wz^T v],
 ``:164-169``, i.e. log|alpha I + Wz Wz^T|) while its exact twin uses beta (``:68``).  ``logdet_beta=True`` (default)
@@ -124,9 +124,9 @@ def alternative_objective_scalable(Z, X, state, alpha, model_type, key, full_set
 # M = Q W (D x d).  Everything D-sized — the factors Wm (d, D) of Z and Wx of the data batch (per-example backward
 # sweeps of the HIP engine), their Gram matrices and M (GEMMs) — is exact linear algebra on the device; what is left
 # is the derivative of the scalar sum_{j,k} <J(z_j) m_jk, L(z_j) e_k> w.r.t. the inputs z_j: a reverse pass over a
-# parameter-JVP, i.e. second order in the network.  The hand-written tapes are first order; this last step runs on
-# torch.func (forward-over-reverse through ``NetSpec.forward`` on the GPU) — the one place of the package where a
-# derivative is not a HIP tape, stated in DESIGN §8 and to be replaced by a second-order tape.
+# parameter-JVP, i.e. second order in the network — ``second_order.input_grad_of_pairing``: the tangent tape is run
+# with per-example directions and every tangent kept, then walked backwards with the adjoint of each op; all
+# convolutions are engine launches (the transposed ones read the HWIO weight tangent in place).
 def _c_out(state, model_type):
     return math.exp(-0.5 * float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0
 
@@ -148,41 +148,13 @@ def _factor_of(state, X, model_type):
 
 
 def _input_grad_of_pairing(state, Z, Mrow, model_type):
-    """grad_Z of  sum_{j,k} < Mrow[(j,k)], W_(j,k)(z_j) >  =  sum_{j,k} < J(z_j) m_jk, c L(z_j) e_k >   (torch.func)."""
-    from torch.func import grad, jvp, vmap
-    net = state.net
-    dev = Mrow.device
-    flat, unravel = flatten_nn_params(state.params)
-    flat = flat.to(device=dev, dtype=torch.float32)
-    stats = state.to(device=dev, dtype=torch.float32).batch_stats
-    root = net.param_root
-    n = Z.shape[0]
-    Kout = net.num_outputs
-    c = _c_out(state, model_type)
-
-    def wrap(theta):
-        tree = unravel(theta)
-        return tree
-
-    def f(theta, z):
-        return net.forward(wrap(theta), stats, z).reshape(-1)               # (K,)
-
-    def phi_one(z, Mj):                                                      # Mj (K rows, D)
-        JM = vmap(lambda m: jvp(lambda th: f(th, z), (flat,), (m,))[1])(Mj)   # (K rows, K): row k = J(z) m_k
-        if model_type == "classifier":
-            p = torch.softmax(f(flat, z), dim=-1)
-            sq = torch.sqrt(p)
-            L = torch.diag(sq) - torch.outer(p, sq)                          # src/ggn.py:27-33, column k = L e_k
-            return (JM * L.T).sum()
-        return c * torch.diagonal(JM).sum()
-
-    Zd = Z.to(device=dev, dtype=torch.float32)
-    Mj = Mrow.reshape(n, Kout, -1)
-    try:
-        return grad(lambda Zb: vmap(phi_one)(Zb, Mj).sum())(Zd)
-    except (RuntimeError, NotImplementedError):
-        # a layer without a batching rule under the nested vmap: one example at a time
-        return torch.stack([grad(lambda z: phi_one(z, Mj[j]))(Zd[j]) for j in range(n)])
+    """grad_Z of  sum_{j,k} < Mrow[(j,k)], W_(j,k)(z_j) >  =  sum_{j,k} < J(z_j) m_jk, c L(z_j) e_k >: reverse mode over
+    the tangent tape on the engine's kernels (``second_order.py``; every convolution / transposed convolution an
+    ``LIP_OP_IGEMM`` through ``lip_engine_run_op``)."""
+    from .ggn import get_engine
+    from .second_order import EngineExecutor, input_grad_of_pairing
+    eng = get_engine(state, Z, model_type)
+    return input_grad_of_pairing(EngineExecutor(eng), Mrow.reshape(eng.n, eng.K, eng.D), _c_out(state, model_type), model_type)
 
 
 def variational_grad_scalable(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None,

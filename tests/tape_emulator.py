@@ -77,7 +77,10 @@ class TapeMachine:
             A = self._gather(seg, P, n, OH, OW)
             Kt = seg.KH * seg.KW * seg.C
             Pb = P if seg.b.pstride != 0 else 1
-            B = self.view(seg.b, Pb, Kt * N).reshape(Pb, Kt, N)
+            if seg.flags & nv.SEG_B_TRANS:          # B[(tap*C + c)][n] = b[(tap*N + n)*C + c]
+                B = self.view(seg.b, Pb, Kt * N).reshape(Pb, seg.KH * seg.KW, N, seg.C).permute(0, 1, 3, 2).reshape(Pb, Kt, N)
+            else:
+                B = self.view(seg.b, Pb, Kt * N).reshape(Pb, Kt, N)
             acc = acc + torch.matmul(A, B)
         v = acc
         if op.scale.space != nv.SP_NONE:

@@ -1,0 +1,100 @@
+"""The second-order pass of the inducing-point gradient (``lip_amd/second_order.py``: reverse mode over the tangent
+tape, every convolution an ``LIP_OP_IGEMM``) against ``torch.func`` differentiation of the same pairing
+phi(Z) = sum_{i,k} < J(z_i) m_ik, c L(z_i) e_k >  (reference: ``jax.value_and_grad`` through
+``src/train_inducing.py:87-173``).  On the CPU the ops run on the float64 tape emulator — this validates the op
+sequence, operand offsets and the adjoint algebra; ``-m gpu`` runs the same ops on the HIP kernels."""
+import math
+
+import pytest
+import torch
+from torch.func import grad, jvp
+
+from lip_amd import second_order as so
+from lip_amd.engine import build_consts, compile_net
+from lip_amd.scalemodels import LargeClassifier, ResNet1M
+from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
+from lip_amd.utils import flatten_nn_params
+from tape_emulator import TapeMachine
+
+F64 = torch.float64
+
+
+def _cases():
+    g = torch.Generator().manual_seed(3)
+    return {
+        "xor_tanh_mlp": (SimpleClassifier(8, 2, 2), torch.randn(4, 2, dtype=F64, generator=g), "classifier"),
+        "sine_gelu_mlp": (SimpleRegressor(6, 2), torch.randn(3, 1, dtype=F64, generator=g), "regressor"),
+        "resnet_bn_res_stride2": (ResNet1M(3, input_shape=(6, 6, 3), widths=(4, 8), blocks_per_stage=1),
+                                  torch.rand(3, 6, 6, 3, dtype=F64, generator=g), "classifier"),
+        "resnet_gray_tiled": (ResNet1M(3, input_shape=(6, 6, 1), widths=(4, 4), blocks_per_stage=1),
+                              torch.rand(2, 6, 6, 1, dtype=F64, generator=g), "classifier"),
+        "flatten_mlp": (LargeClassifier((3, 3, 1), [5, 4], 2, 3), torch.rand(3, 3, 3, 1, dtype=F64, generator=g), "classifier"),
+    }
+
+
+def _reference(st, Z, Mdir, c, model_type):
+    """grad_Z of the pairing by forward-over-reverse torch.func on the functional forward, float64."""
+    net = st.net
+    flat, unravel = flatten_nn_params(st.params)
+
+    def f(theta, z):
+        return net.forward(unravel(theta), st.batch_stats, z).reshape(-1)
+
+    def phi_one(z, Mj):
+        JM = torch.stack([jvp(lambda th: f(th, z), (flat,), (m,))[1] for m in Mj])        # row k = J(z) m_k
+        if model_type == "classifier":
+            p = torch.softmax(f(flat, z), dim=-1)
+            sq = torch.sqrt(p)
+            L = torch.diag(sq) - torch.outer(p, sq)
+            return c * (JM * L.T).sum()
+        return c * torch.diagonal(JM).sum()
+
+    return torch.stack([grad(lambda z: phi_one(z, Mdir[j]))(Z[j]) for j in range(Z.shape[0])])
+
+
+class _EmulatorExecutor:
+    def __init__(self, cn, st, Z, K):
+        flat, _ = flatten_nn_params(st.params)
+        self.tm = TapeMachine(cn, flat, build_consts(cn, st.params, st.batch_stats, "cpu", F64), Z, chunk=K)
+        self.tm.primal()
+        self.cn, self.device, self.dtype = cn, torch.device("cpu"), F64
+        self.prim, self.consts, self.theta = self.tm.prim, self.tm.consts, self.tm.theta
+        self.max_probes = K
+
+    def run(self, op, P, V, Y):
+        self.tm.V, self.tm.Y = V.reshape(-1), Y
+        self.tm.run_op(op, P)
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_second_order_pass_on_the_tape_emulator(name):
+    net, Z, mt = _cases()[name]
+    st = create_state(net, 5, dtype=F64, logvar=-0.4)
+    n = Z.shape[0]
+    cn = compile_net(net, n, st.params)
+    Mdir = torch.randn(n, cn.K, cn.D, dtype=F64, generator=torch.Generator().manual_seed(9))
+    c = math.exp(0.2) if mt == "regressor" else 1.0
+    ex = _EmulatorExecutor(cn, st, Z, cn.K)
+    got = so.input_grad_of_pairing(ex, Mdir, c, mt)
+    ref = _reference(st, Z, Mdir, c, mt)
+    assert got.shape == Z.shape
+    assert (got - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(_cases()) + ["resnet_fast_kernels"])
+def test_second_order_pass_on_the_hip_engine(name):
+    from lip_amd.engine import LinearizedNet
+    if name == "resnet_fast_kernels":          # channel counts that take the straight-line MFMA kernels for the shared-weight ops
+        net, Z, mt = ResNet1M(4, input_shape=(8, 8, 3), widths=(16, 32), blocks_per_stage=1), \
+            torch.rand(3, 8, 8, 3, dtype=F64, generator=torch.Generator().manual_seed(4)), "classifier"
+    else:
+        net, Z, mt = _cases()[name]
+    st = create_state(net, 5, dtype=F64, logvar=-0.4)
+    n = Z.shape[0]
+    eng = LinearizedNet(st.to(device="cuda", dtype=torch.float32), Z.cuda().float(), mt, workspace_bytes=1 << 28, max_chunk=16)
+    Mdir = torch.randn(n, eng.K, eng.D, dtype=F64, generator=torch.Generator().manual_seed(9))
+    c = math.exp(0.2) if mt == "regressor" else 1.0
+    got = so.input_grad_of_pairing(so.EngineExecutor(eng), Mdir.cuda().float(), c, mt).double().cpu()
+    ref = _reference(st, Z, Mdir, c, mt)
+    assert (got - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
