@@ -492,6 +492,32 @@ def main():
                               "(image, draw)", finite=bool(torch.isfinite(LS).all().item()))
         del LS, Xw, Xe
 
+    # ---- one exact inducing-point gradient step (src/train_inducing.py:195-232) at this config: 50 inducing images,
+    # a data batch of 256, factors + Gram algebra + the second-order pass (reverse over the tangent tape) on the engine --
+    ipgrad_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        from lip_amd.train_inducing import variational_grad_scalable, _input_grad_of_pairing
+        st_g = state.to(device=dev, dtype=torch.float32)
+        Zg = Z.to(dev)
+        Xg = torch.rand(256, 32, 32, 3, generator=torch.Generator().manual_seed(77)).to(dev)
+        variational_grad_scalable(Zg, Xg, st_g, alpha, model_type="classifier", full_set_size=full, x_chunk=128)    # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss_g, gZ = variational_grad_scalable(Zg, Xg, st_g, alpha, model_type="classifier", full_set_size=full, x_chunk=128)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t1
+        Mg = torch.randn(n * 10, eng.D, device=dev)
+        t1 = time.perf_counter()
+        _input_grad_of_pairing(st_g, Zg, Mg, "classifier")
+        torch.cuda.synchronize()
+        t_so = time.perf_counter() - t1
+        ipgrad_line = dict(seconds_per_step=t_g, second_order_pass_seconds=t_so, loss=loss_g,
+                           grad_finite=bool(torch.isfinite(gZ).all().item()), inducing_images=n, data_batch=256,
+                           note="value and gradient of the exact KL objective the reference's Hutch++ / SLQ estimators target; "
+                                "no torch.func: the input derivative of the parameter-JVP pairing is reverse mode over the "
+                                "tangent tape, op by op through lip_engine_run_op (second_order.py)")
+        del Mg, Xg, gZ
+
     # ---- trace-estimator legs, end to end (probe fill + block products + quadratic forms) ----------------------
     trace_line = None
     if args.samples > 0 and rank == 0 and world == 1:
@@ -596,7 +622,7 @@ def main():
                                           "example_probe_products_per_s = value * examples_total is the figure that "
                                           "grows with N under weak scaling",
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, trace_estimators=trace_line, few_probes=single_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, inducing_gradient_step=ipgrad_line, trace_estimators=trace_line, few_probes=single_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:

@@ -82,7 +82,7 @@ def test_eigh_sampler_against_matrix_free_operator(setup):
     m["lam_checked"] = lam_k.tolist()
     print("SAMPLER_FULLSIZE eigh " + json.dumps(m))
     eps = 2.0 ** -24
-    assert m["eigpair_residual"] <= 2e-4
+    assert m["eigpair_residual"] <= 5e-4          # measured 7e-5 .. 1.6e-4 over boxes (the weakest kept direction sets it)
     # floor: eps * sqrt(cond) = 3.3e-3 of a unit coefficient; coefficients down to 0.1 units are in the maximum
     assert m["stiff_direction_error"] <= 5e-2
     # whitening: float32 factor rows and two float32 GEMM passes over D = 1.08 M; A^(1/2)-weighted error per draw is
@@ -119,7 +119,7 @@ def test_lanczos_sampler_against_matrix_free_operator(setup, alpha, k):
     Vd, gram = s["V"].double(), X.double() @ A(X).double().T
     m["energy_identity"] = ((gram.diagonal() - (Vd * Vd).sum(1)).abs() / (Vd * Vd).sum(1)).max().item()
     print(f"SAMPLER_FULLSIZE lanczos alpha={alpha} k={k} " + json.dumps(m))
-    tol_energy, tol_diff = (2e-3, 0.03) if alpha >= 1.0 else (2e-2, 0.03)
+    tol_energy, tol_diff = (2e-3, 0.03) if alpha >= 1.0 else (3e-2, 0.04)     # measured 4e-6 .. 4e-4 / 6e-4 and 6e-3 .. 1.1e-2 / 1.9e-2
     assert m["energy_identity"] <= tol_energy
     # the draws agree with the exact small-space sampler up to the part of v in range(W) (a fraction sqrt(d / D) ~ 2 %
     # of ||v||) that k steps have not resolved
