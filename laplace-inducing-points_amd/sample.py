@@ -187,8 +187,14 @@ class _SamplerParts:
             X = (x1 - a * x2).float().contiguous()
         return X, self.Wm
 
+    def _degenerate(self) -> bool:
+        """no direction of positive curvature kept (a zero Jacobian): A = alpha I"""
+        return self.method == "eigh" and self.Qm is not None and self.Qm.shape[0] == 0
+
     def apply(self, V: torch.Tensor) -> torch.Tensor:
         """rows of V (S, D) -> A^(-1/2) V"""
+        if self._degenerate():
+            return V / math.sqrt(self.alpha)
         T, B = self._correction(V)
         a = 1.0 / math.sqrt(self.alpha)
         if B is not None:
@@ -199,6 +205,8 @@ class _SamplerParts:
     def apply_(self, V: torch.Tensor) -> torch.Tensor:
         """In-place :meth:`apply` for the materialised-factor case: the ``+ alpha^(-1/2) v`` term rides in the second
         GEMM's epilogue (``beta * C``), so a block of draws costs two GEMM passes over the factor and nothing else."""
+        if self._degenerate():
+            return V.mul_(1.0 / math.sqrt(self.alpha))
         T, B = self._correction(V)
         if B is None:
             V.copy_(self.apply(V))
