@@ -12,8 +12,9 @@ the directions m_ik = (Q W)_(i,k) are frozen, see ``train_inducing.py``).  It is
             Z' = Y + sum_k (dgamma_ik / gamma) DY_k                      (BN: xhat depends on z)
             DA_{l-1} += convT(s DY, W) ;  A_{l-1} += convT(s Z', W) + sum_k convT(s DY_k, dW_ik)
 
-The direction differs per EXAMPLE, so the segments with a weight tangent run one launch per example (``n_img = 1``,
-operand offsets shifted to example i); the shared-weight segments run over all examples at once.  Every convolution
+The direction differs per EXAMPLE, so the segments with a weight tangent run with the examples on the probe axis
+(``n_img = 1``, one launch per direction k: "probe" i reads a_i and dW_ik — every operand offset is linear in i); the
+shared-weight segments run over all examples at once.  Every convolution
 / transposed convolution is an ``LIP_OP_IGEMM`` launched through ``lip_engine_run_op`` — the transposed ones read
 the HWIO kernel in place (``LIP_SEG_B_TRANS``: a weight tangent has no transposed copy) — the per-element glue between
 them (act', act'', BN factors, sums over the K probes) is torch algebra on the arena the ops read and write.
@@ -217,10 +218,14 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         if shared:   # conv(da, W) over all examples
             ex.run(_igemm(n, oh, ow, co, dict(geom(u), a=Y(f"T{src}", 0, n * ssz), b=_ref(nv.SP_THETA, poff(u.kernel))),
                           Y("ACC", 0, n * sz)), K, Mdir, arena)
-        for i in range(n):   # + conv(a_i, dW_ik): the weight tangent is the example's own
-            seg = dict(geom(u), a=_ref(nv.SP_PRIM, cn.a_off[u.src] + i * ssz), b=_ref(nv.SP_VIN, i * K * D + poff(u.kernel), D))
-            o = Y("ACC", i * sz, n * sz)
-            ex.run(_igemm(1, oh, ow, co, seg, o, res=o if shared else None), K, Mdir, arena)
+        # + conv(a_i, dW_ik): the weight tangent is the example's own.  One launch per direction k with the EXAMPLES on
+        # the probe axis (n_img = 1, "probe" i reads a_i, dW_ik and writes slot (k, i)): every operand offset is linear in i
+        for k in range(K):
+            for i0 in range(0, n, ex.max_probes):
+                seg = dict(geom(u), a=_ref(nv.SP_PRIM, cn.a_off[u.src] + i0 * ssz, ssz),
+                           b=_ref(nv.SP_VIN, (i0 * K + k) * D + poff(u.kernel), K * D))
+                o = Y("ACC", (k * n + i0) * sz, sz)
+                ex.run(_igemm(1, oh, ow, co, seg, o, res=o if shared else None), min(ex.max_probes, n - i0), Mdir, arena)
         a, dphi, _ = unit_primals(u)
         dy = acc.view(K, n, oh * ow, co)
         bn = bn_factors(u)
@@ -300,9 +305,10 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         ex.run(_igemm(n, sh, sw, sc, dict(geom_t(u), a=Y("SZB", 0, 0), b=wref), Y("TMP", 0, 0)), 1, Mdir, arena)
         buf(f"A{src}", n, ssz).add_(buf("TMP", n, ssz))
         # A_src_i += sum_k convT(s DY_ik, dW_ik)
-        for i in range(n):
-            seg = dict(geom_t(u), a=Y("SDY", i * sz, n * sz), b=_ref(nv.SP_VIN, i * K * D + poff(u.kernel), D))
-            ex.run(_igemm(1, sh, sw, sc, seg, Y("TMP", i * ssz, n * ssz)), K, Mdir, arena)
+        for k in range(K):   # examples on the probe axis, as in the forward pass
+            for i0 in range(0, n, ex.max_probes):
+                seg = dict(geom_t(u), a=Y("SDY", (k * n + i0) * sz, sz), b=_ref(nv.SP_VIN, (i0 * K + k) * D + poff(u.kernel), K * D))
+                ex.run(_igemm(1, sh, sw, sc, seg, Y("TMP", (k * n + i0) * ssz, ssz)), min(ex.max_probes, n - i0), Mdir, arena)
         buf(f"A{src}", n, ssz).add_(tmp.sum(0))
 
     h0, w0, c0 = tens[0]
