@@ -111,12 +111,9 @@ def predict_lla_scalable(map_state, Xnew, Z, model_type, alpha, key=None, full_s
 
 
 def _cross_gram64(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
-    """A B^T for (a, D), (b, D) float32 factors with float64 accumulation over slabs of the long axis."""
-    out = torch.zeros(A.shape[0], B.shape[0], device=A.device, dtype=torch.float64)
-    step = max(1, (512 << 20) // (8 * max(A.shape[0], B.shape[0])))
-    for c in range(0, A.shape[1], step):
-        out += A[:, c:c + step].double() @ B[:, c:c + step].double().T
-    return out
+    """A B^T for (a, D), (b, D) float32 factors with float64 accumulation (``lip_dot_nt_f64``)."""
+    from . import krylov
+    return krylov.dot_nt(A.contiguous(), B.contiguous())
 
 
 def predict_lla_marginals(map_state, Xnew, Z, model_type, alpha, full_set_size=None, batch: int = 64):
