@@ -368,7 +368,7 @@ def compile_net(net: NetSpec, n: int, params: Dict[str, Any]) -> CompiledNet:
     return CompiledNet(net=net, n=n, D=D, K=K, classifier=classifier, offsets=layout, prim_floats=max(prim, 4),
                        const_floats=cst, work_pp=work_pp, tapes=tapes, a_off=a_off, const_plan=const_plan,
                        prob_off=prob_off, input_off=a_off[0],
-                       meta=dict(dphi_off=dphi_off, xhat_off=xhat_off, s_off=s_off, rstd_off=rstd_off, wt_off=wt_off,
+                       meta=dict(dphi_off=dphi_off, xhat_off=xhat_off, s_off=s_off, rstd_off=rstd_off, wt_off=wt_off, amax_off=amax_off,
                                  sqrtp_off=sqrtp_off, layout=layout))
 
 

@@ -20,8 +20,8 @@ the HWIO kernel in place (``LIP_SEG_B_TRANS``: a weight tangent has no transpose
 them (act', act'', BN factors, sums over the K probes) is torch algebra on the arena the ops read and write.
 
 Supported: the units of the reference's MLPs and ResNet1M (Dense / conv with bias or eval-mode BN, residual adds,
-ReLU / tanh / identity anywhere, GELU on Dense layers, global mean pool, flatten views); window pools (LeNet5, the
-ResNet-50 stem) are refused.
+ReLU / tanh / identity anywhere, GELU on Dense layers, global mean pool, flatten views) and the window pools of
+LeNet5 / the ResNet-50 stem (max pool is piecewise linear: tangents and adjoints gather / scatter at the cached argmax).
 """
 from __future__ import annotations
 
@@ -70,6 +70,27 @@ def _igemm(n_img, OH, OW, N, seg, out, res=None):
     o.out = out
     if res is not None:
         o.res = res
+    return o
+
+
+def _pool(kind, n_img, u, tens, a_ref, out_ref, amax):
+    """window pool of unit u (``LIP_OP_MAXPOOL_FWD``: gather at the cached argmax / window average) or its transpose
+    (``LIP_OP_MAXPOOL_BWD``) — both linear in the pooled tensor, so they serve tangents and adjoints alike."""
+    o = nv.Op()
+    o.kind, o.nseg = kind, 1
+    for name in nv.REF_FIELDS:
+        setattr(o, name, NONE)
+    for i in range(3):
+        o.seg[i].a = NONE
+        o.seg[i].b = NONE
+    ih, iw, cc = tens[u.src]
+    oh, ow, _ = tens[u.dst]
+    sg = o.seg[0]
+    sg.a = a_ref
+    sg.IH, sg.IW, sg.C, sg.KH, sg.KW, sg.stride, sg.pad_h, sg.pad_w = ih, iw, cc, u.kh, u.kw, u.stride, u.pad_h, u.pad_w
+    o.n_img, o.OH, o.OW, o.N = int(n_img), oh, ow, cc
+    o.out = out_ref
+    o.aux0 = amax
     return o
 
 
@@ -209,8 +230,14 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
             Ts = buf(f"T{src}", K, n, h * w, c)
             buf(f"T{dst}", K, n, c).copy_(Ts.mean(2))
             continue
+        if u.kind in ("maxpool", "avgpool"):
+            am = meta["amax_off"][dst]
+            amax = NONE if am is None else _ref(nv.SP_PRIM, am)
+            ex.run(_pool(nv.OP_MAXPOOL_FWD, n, u, tens, Y(f"T{src}", 0, n * size(u.src)), Y(f"T{dst}", 0, n * size(dst)), amax),
+                   K, Mdir, arena)
+            continue
         if u.kind != "conv":
-            raise NotImplementedError(f"second-order pass: unit kind '{u.kind}' (window pools) is not supported")
+            raise NotImplementedError(f"second-order pass: unit kind '{u.kind}' is not supported")
         oh, ow, co = tens[dst]
         sz, ssz = size(dst), size(u.src)
         acc = buf("ACC", K, n, sz)
@@ -270,6 +297,16 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
             if has_tan[u.src]:
                 buf(f"DA{src}", K, n, h * w, c).add_(buf(f"DA{dst}", K, n, 1, c) / (h * w))
             buf(f"A{src}", n, h * w, c).add_(buf(f"A{dst}", n, 1, c) / (h * w))
+            continue
+        if u.kind in ("maxpool", "avgpool"):
+            am = meta["amax_off"][dst]
+            amax = NONE if am is None else _ref(nv.SP_PRIM, am)
+            sz, ssz = size(dst), size(u.src)
+            if has_tan[u.src]:
+                ex.run(_pool(nv.OP_MAXPOOL_BWD, n, u, tens, Y(f"DA{dst}", 0, n * sz), Y("TMP", 0, n * ssz), amax), K, Mdir, arena)
+                buf(f"DA{src}", K, n, ssz).add_(buf("TMP", K, n, ssz))
+            ex.run(_pool(nv.OP_MAXPOOL_BWD, n, u, tens, Y(f"A{dst}", 0, 0), Y("TMP", 0, 0), amax), 1, Mdir, arena)
+            buf(f"A{src}", n, ssz).add_(buf("TMP", n, ssz))
             continue
         oh, ow, co = tens[dst]
         sz, ssz = size(dst), size(u.src)

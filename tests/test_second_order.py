@@ -29,7 +29,38 @@ def _cases():
         "resnet_gray_tiled": (ResNet1M(3, input_shape=(6, 6, 1), widths=(4, 4), blocks_per_stage=1),
                               torch.rand(2, 6, 6, 1, dtype=F64, generator=g), "classifier"),
         "flatten_mlp": (LargeClassifier((3, 3, 1), [5, 4], 2, 3), torch.rand(3, 3, 3, 1, dtype=F64, generator=g), "classifier"),
+        "lenet_avgpool_flatdense": (_mini_lenet(), torch.rand(2, 12, 12, 1, dtype=F64, generator=g), "classifier"),
+        "stem_maxpool": (_mini_stem(), torch.rand(2, 9, 9, 3, dtype=F64, generator=g), "classifier"),
     }
+
+
+def _mini_lenet():
+    """LeNet5's structure (src/scalemodels.py:11-49) at test size: conv + bias + ReLU, 2x2 average pool, Dense on the
+    flattened map, Dense."""
+    from lip_amd.netspec import NetSpec
+    net = NetSpec((12, 12, 1))
+    x = net.conv(0, "Conv_0", 3, 5, 1, padding=2, act="relu", use_bias=True)
+    x = net.avgpool(x, 2, 2)
+    x = net.conv(x, "Conv_1", 4, 3, 1, padding="VALID", act="relu", use_bias=True)
+    x = net.avgpool(x, 2, 2)
+    x = net.dense(x, "Dense_0", 6, act="relu")
+    net.dense(x, "Dense_1", 3)
+    net.model_type = "classifier"
+    return net
+
+
+def _mini_stem():
+    """the ResNet-50 stem's pattern: strided conv + BN + ReLU, overlapping 3x3 / 2 max pool with padding, then a
+    conv, mean pool and Dense."""
+    from lip_amd.netspec import NetSpec
+    net = NetSpec((9, 9, 3))
+    x = net.conv(0, "Conv_0", 4, 3, 2, padding=1, bn="BatchNorm_0", act="relu")
+    x = net.maxpool(x, 3, 2, padding=1)
+    x = net.conv(x, "Conv_1", 4, 3, 1, padding=1, bn="BatchNorm_1", act="relu")
+    x = net.meanpool(x)
+    net.dense(x, "Dense_0", 3)
+    net.model_type = "classifier"
+    return net
 
 
 def _reference(st, Z, Mdir, c, model_type):
