@@ -758,6 +758,218 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
 }
 
 // ------------------------------------------------------------------------------------------
+// implicit GEMM with the A operand straight from global memory into the MFMA operand registers (tiles whose waves
+// own disjoint rows: four waves stacked along M, 32 or 64 columns).  In igemm_fast_kernel the gathered activation
+// tile goes registers -> LDS (transposing store) -> registers although no wave ever reads another wave's rows: LDS is
+// only a transposer there.  v_mfma_f32_32x32x2_f32 takes A[i = lane & 31][k = lane >> 5]; which two k's of the 16-deep
+// K-tile an instruction consumes is free as long as B follows, so lane-half h takes the CONTIGUOUS channels
+// 8h .. 8h+7 of its row: two 16-byte loads per K-tile ARE the eight A operands of the sweep (k-step kk multiplies
+// A[row][8h + kk] with B[8h + kk][n]).  Only B (16 x BN, shared by the four waves) still goes through LDS.
+// Per K-tile and lane: 2 global loads + BE/BW B loads, BE/BW LDS stores, 8 TN LDS reads, 8 TN MFMAs — the fast kernel
+// issues 8 more LDS stores and 8 more LDS reads.  Register tiles are three deep (tile t+3 requested after the sweep
+// of tile t), B rides along in the same cadence through a double LDS buffer.
+// ------------------------------------------------------------------------------------------
+template <int TM, int TN, bool BV>
+__global__ __launch_bounds__(256) void igemm_adirect_kernel(const IgemmP prm) {
+  constexpr int NT = 256, BM = 128 * TM, BN = 32 * TN;
+  constexpr int AR = 8 * TM;                                  // A operand registers per K-tile: 8 channels of TM rows
+  constexpr int BE = BN * BK / NT;                            // B floats per thread per K-tile (2 or 4)
+  constexpr int BW = BV ? (BE >= 4 ? 4 : BE) : 1;
+  constexpr int NB = BE / BW;
+  constexpr int LDB = BN, BSZ = BK * LDB;
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+  __shared__ float redbuf[2 * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int N = prm.N, R = prm.R;
+  const int tiles_n = (N + BN - 1) / BN;
+  int bid = blockIdx.x, byp = blockIdx.y;
+  {   // XCD-contiguous order, as in igemm_fast_kernel
+    const int gx = (int)gridDim.x;
+    if (gx >= 64) {
+      const int g8 = gx & ~7;
+      if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+    } else {
+      const int g8 = (gx * (int)gridDim.y) & ~7, lin = bid + gx * byp;
+      if (lin < g8) {
+        const int w = (lin & 7) * (g8 >> 3) + (lin >> 3);
+        byp = w / gx; bid = w - byp * gx;
+      }
+    }
+  }
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int p = byp;
+  const int r0 = tile_m * BM, n0 = tile_n * BN;
+
+  for (int i = tid; i < 2 * BN; i += NT) redbuf[i] = 0.f;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  // this lane's TM rows and its 8-channel half
+  int vi[TM], voh[TM], vow[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = r0 + (wm * TM + tm) * 32 + l31;
+    if (r < R) {
+      const int i = prm.dOHW.div(r), rem = r - i * prm.OHW;
+      vi[tm] = i; voh[tm] = prm.dOW.div(rem); vow[tm] = rem - voh[tm] * prm.OW;
+    } else {
+      vi[tm] = -1; voh[tm] = 0; vow[tm] = 0;
+    }
+  }
+  unsigned bidx[NB];
+  bool bok[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e = tid + j * NT;
+    if (BW > 1) {
+      const int k = e / (BN / BW), nq = e - k * (BN / BW);
+      bok[j] = (n0 + BW * nq) < N;
+      bidx[j] = (unsigned)(k * N + n0 + BW * nq);
+    } else {
+      const int k = e / BN, nn = e - k * BN;
+      bok[j] = (n0 + nn) < N;
+      bidx[j] = (unsigned)(k * N + n0 + nn);
+    }
+  }
+
+  int rowoff[TM];
+  bool rowok[TM];
+  int seg = 0, kh = 0, kw = 0, c0 = 0;
+  const float* abase = nullptr;
+  const float* bbase = nullptr;
+  int sIH = 0, sIW = 0, sC = 0, sKH = 0, sKW = 0, smul = 0, ssgn = 0, soffh = 0, soffw = 0, smask = 0, ssh = 0;
+
+  auto begin_segment = [&]() __attribute__((always_inline)) {
+    const SegP& s = prm.seg[seg];
+    abase = s.a + (long long)p * s.a_ps;
+    bbase = s.b + (long long)p * s.b_ps;
+    sIH = s.IH; sIW = s.IW; sC = s.C; sKH = s.KH; sKW = s.KW;
+    smul = s.mul; ssgn = s.sgn; soffh = s.off_h; soffw = s.off_w; smask = s.mask; ssh = s.sh;
+    kh = 0; kw = 0; c0 = 0;
+  };
+  auto set_tap = [&]() __attribute__((always_inline)) {
+    const int th = ssgn * kh + soffh, tw = ssgn * kw + soffw;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int t0h = voh[tm] * smul + th, t0w = vow[tm] * smul + tw;
+      const int ih = t0h >> ssh, iw = t0w >> ssh;
+      rowok[tm] = (vi[tm] >= 0) && (((t0h | t0w) & smask) == 0) && ((unsigned)ih < (unsigned)sIH) && ((unsigned)iw < (unsigned)sIW);
+      rowoff[tm] = rowok[tm] ? ((vi[tm] * sIH + ih) * sIW + iw) * sC + 8 * lh : 0;
+    }
+  };
+  auto load_tile = [&](float (&areg)[AR], float (&breg)[BE]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float* src = rowok[tm] ? (abase + c0 + (unsigned)rowoff[tm]) : prm.zeros;      // masked rows read the zero page
+      const float4 v0 = *reinterpret_cast<const float4*>(src);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+      areg[8 * tm + 0] = v0.x; areg[8 * tm + 1] = v0.y; areg[8 * tm + 2] = v0.z; areg[8 * tm + 3] = v0.w;
+      areg[8 * tm + 4] = v1.x; areg[8 * tm + 5] = v1.y; areg[8 * tm + 6] = v1.z; areg[8 * tm + 7] = v1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float* bs = bok[j] ? (bbase + bidx[j]) : prm.zeros;
+      if (BW == 4) {
+        const float4u v = *reinterpret_cast<const float4u*>(bs);
+        breg[4 * j + 0] = v[0]; breg[4 * j + 1] = v[1]; breg[4 * j + 2] = v[2]; breg[4 * j + 3] = v[3];
+      } else if (BW == 2) {
+        const float2u v = *reinterpret_cast<const float2u*>(bs);
+        breg[2 * j + 0] = v[0]; breg[2 * j + 1] = v[1];
+      } else {
+        breg[j] = *bs;
+      }
+    }
+  };
+  auto store_b = [&](const float (&breg)[BE], float* Bsb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int e = tid + j * NT;
+      if (BW == 4) {
+        const int k = e / (BN / 4), nq = e - k * (BN / 4);
+        *reinterpret_cast<float4*>(&Bsb[k * LDB + 4 * nq]) = make_float4(breg[4 * j + 0], breg[4 * j + 1], breg[4 * j + 2], breg[4 * j + 3]);
+      } else if (BW == 2) {
+        const int k = e / (BN / 2), nq = e - k * (BN / 2);
+        *reinterpret_cast<float2*>(&Bsb[k * LDB + 2 * nq]) = make_float2(breg[2 * j + 0], breg[2 * j + 1]);
+      } else {
+        const int k = e / BN, nn = e - k * BN;
+        Bsb[k * LDB + nn] = breg[j];
+      }
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    c0 += BK;
+    bbase += BK * N;
+    if (c0 == sC) {
+      c0 = 0;
+      if (++kw == sKW) { kw = 0; ++kh; }
+      if (kh == sKH) { ++seg; begin_segment(); }
+      set_tap();
+    }
+  };
+  auto sweep = [&](const float (&areg)[AR], const float* Bsb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float b[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = Bsb[(8 * lh + kk) * LDB + tn * 32 + l31];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[8 * tm + kk], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  int T = 0;
+  for (int q = 0; q < prm.nseg; ++q) T += prm.seg[q].Ktot / BK;
+
+  float a0[AR], a1[AR], a2[AR], b0[BE], b1[BE], b2[BE];
+  begin_segment();
+  set_tap();
+  load_tile(a0, b0);
+  store_b(b0, Bs);
+  if (T > 1) { advance(); load_tile(a1, b1); }
+  if (T > 2) { advance(); load_tile(a2, b2); }
+  __syncthreads();
+  // iteration t: A of tile t in set t % 3, B of tile t in LDS buffer t & 1, B of tile t+1 in register set (t+1) % 3
+#define LIP_AD_ITER(CUR, NXT, AC, BC, BNX, DO_STORE, DO_LOAD)                     \
+  do {                                                                            \
+    if (DO_STORE) store_b(BNX, Bs + (NXT) * BSZ);                                 \
+    sweep(AC, Bs + (CUR) * BSZ);                                                  \
+    if (DO_LOAD) { advance(); load_tile(AC, BC); }                                \
+    __syncthreads();                                                              \
+  } while (0)
+  int t = 0;
+  while (t + 8 < T) {
+    LIP_AD_ITER(0, 1, a0, b0, b1, true, true);
+    LIP_AD_ITER(1, 0, a1, b1, b2, true, true);
+    LIP_AD_ITER(0, 1, a2, b2, b0, true, true);
+    LIP_AD_ITER(1, 0, a0, b0, b1, true, true);
+    LIP_AD_ITER(0, 1, a1, b1, b2, true, true);
+    LIP_AD_ITER(1, 0, a2, b2, b0, true, true);
+    t += 6;
+  }
+  while (t < T) {
+    LIP_AD_ITER(0, 1, a0, b0, b1, t + 1 < T, t + 3 < T); if (++t >= T) break;
+    LIP_AD_ITER(1, 0, a1, b1, b2, t + 1 < T, t + 3 < T); if (++t >= T) break;
+    LIP_AD_ITER(0, 1, a2, b2, b0, t + 1 < T, t + 3 < T); if (++t >= T) break;
+    LIP_AD_ITER(1, 0, a0, b0, b1, t + 1 < T, t + 3 < T); if (++t >= T) break;
+    LIP_AD_ITER(0, 1, a1, b1, b2, t + 1 < T, t + 3 < T); if (++t >= T) break;
+    LIP_AD_ITER(1, 0, a2, b2, b0, t + 1 < T, t + 3 < T); ++t;
+  }
+#undef LIP_AD_ITER
+  igemm_epilogue<4, 1, TM, TN, false>(prm, acc, redbuf, p, r0, n0, wm, 0, lane, tid);
+}
+
+// ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN>
@@ -1338,6 +1550,15 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       q.dOHW2 = FastDiv((unsigned)q.OHW2); q.dOW2 = FastDiv((unsigned)q.OW2);
       grid.x = (unsigned)(4ll * ((q.Rc + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN));
     }
+    if constexpr (WM == 4 && WN == 1) {
+      // A operand straight into the MFMA registers (A/B switch LIP_NOADIRECT)
+      static const bool noad = getenv("LIP_NOADIRECT") != nullptr;
+      if (!noad && !split && !par && !dbg) {
+        if (bv4) hipLaunchKernelGGL((igemm_adirect_kernel<TM, TN, true>), grid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((igemm_adirect_kernel<TM, TN, false>), grid, dim3(256), 0, st, q);
+        return hipGetLastError();
+      }
+    }
 #define LIP_LAUNCH_IGEMM(S_, P_, V_) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, S_, P_, V_>), grid, dim3(T::NT), 0, st, q)
     if (split) {
       if (par) LIP_LAUNCH_IGEMM(true, true, false); else LIP_LAUNCH_IGEMM(true, false, false);
@@ -1404,7 +1625,7 @@ hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   if (tile_override() == 3 && p.N <= 32) return run_igemm<1, 1, 2, 1>(p, P, st);
   if (tile_override() == 4 && p.N <= 32) return run_igemm<2, 1, 1, 1>(p, P, st);
   const bool small_m = p.R <= 64;
-  const bool big_m = p.R >= 4096 && tile_override() == 1;    // LIP_TILE=1: 256-row tiles (A/B: 15% slower on MI355X, r2)
+  const bool big_m = p.R >= 4096 && (tile_override() == 1 || (tile_override() == 5 && p.N <= 32) || tile_override() == 6);    // LIP_TILE=1: 256-row tiles (A/B: 15% slower on MI355X, r2)
   if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);
   if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 2>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st));
   return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st));
