@@ -1625,7 +1625,7 @@ hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   if (tile_override() == 3 && p.N <= 32) return run_igemm<1, 1, 2, 1>(p, P, st);
   if (tile_override() == 4 && p.N <= 32) return run_igemm<2, 1, 1, 1>(p, P, st);
   const bool small_m = p.R <= 64;
-  const bool big_m = p.R >= 4096 && tile_override() == 1;    // LIP_TILE=1: 256-row tiles (A/B: slower on every shape, r1 and r2)    // LIP_TILE=1: 256-row tiles (A/B: 15% slower on MI355X, r2)
+  const bool big_m = p.R >= 4096 && tile_override() == 1;    // LIP_TILE=1: 256-row tiles (A/B: slower on every shape, r1 and r2)
   if (p.N > 64) return small_m ? run_igemm<2, 2, 1, 2>(p, P, st) : run_igemm<2, 2, 2, 2>(p, P, st);
   if (p.N > 32) return small_m ? run_igemm<2, 2, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 2>(p, P, st) : run_igemm<4, 1, 1, 2>(p, P, st));
   return small_m ? run_igemm<2, 1, 1, 1>(p, P, st) : (big_m ? run_igemm<4, 1, 2, 1>(p, P, st) : run_igemm<4, 1, 1, 1>(p, P, st));

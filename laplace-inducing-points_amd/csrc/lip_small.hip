@@ -94,15 +94,28 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolP prm) {
   const long long base = ((long long)i * prm.HW + pbeg) * C;
   float* out = prm.out + (long long)p * prm.out_ps + base;
   const long long cnt = (long long)npix * C;
+  // 256 % C == 0: a thread keeps ONE channel for all its pixels, so the column sums accumulate in registers and
+  // reach LDS once per thread (an LDS atomic per element made this broadcast kernel run at 0.4 TB/s)
+  const bool fixed_c = (256 % C) == 0;
+  float a0 = 0.f, a1 = 0.f;
   for (long long idx = threadIdx.x; idx < cnt; idx += 256) {
     const int c = (int)(idx % C);
     float v = in[c] * prm.inv;
     if (prm.dphi) v *= prm.dphi[base + idx];
     out[idx] = v;
     if (red) {
-      atomicAdd(&s0[c], v);
-      if (prm.red1) atomicAdd(&s1[c], v * prm.xhat[base + idx]);
+      const float x = prm.red1 ? v * prm.xhat[base + idx] : 0.f;
+      if (fixed_c) { a0 += v; a1 += x; }
+      else {
+        atomicAdd(&s0[c], v);
+        if (prm.red1) atomicAdd(&s1[c], x);
+      }
     }
+  }
+  if (red && fixed_c && threadIdx.x < cnt) {
+    const int c = threadIdx.x % C;
+    atomicAdd(&s0[c], a0);
+    if (prm.red1) atomicAdd(&s1[c], a1);
   }
   if (red) {
     __syncthreads();
