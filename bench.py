@@ -609,6 +609,10 @@ def main():
         line = dict(metric="GGN-vector products/sec", value=value, example_probe_products_per_s=value * n_total,
                     per_shard_products_per_s=per_shard, unit="GGN-vp/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
+                    scaling_note="weak scaling in the DATA sum: per-GPU work is fixed (50 examples x P probes), the data set "
+                                 "grows with N, so `value` (products over the whole set per second) stays flat when scaling "
+                                 "is perfect — it is step time that should stay constant; the throughput that grows with N "
+                                 "is example_probe_products_per_s (= value x 50 N)",
                     vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload="CIFAR-CNN ResNet1M GGN-vp (BASELINE configs[3]): D=1084586, "
                                          f"n={n} examples/GPU, P={P} Rademacher probes/block, alpha=0.005, "
