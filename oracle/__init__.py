@@ -25,6 +25,12 @@ reference's own tests hold, restated in ``tests/test_oracle_*.py``
   * Lanczos inverse square root on diag(1..100)/100, 20 steps, rtol 1e-1
     (``tests/test_sample.py:334-355``);
   * sampler moments vs dense posterior, atol 1e-1 (``tests/test_sample.py:467-508``).
+The reference's known answers are all regressor / dense-matrix cases; the softmax Hessian and its square-root
+forms, eval-mode BN, strided SAME convolutions, residual adds and the flat-theta order are pinned in addition by
+anchors written by hand WITHOUT this package and without ``NetSpec.forward`` (``tests/test_oracle_anchors.py``):
+a linear softmax classifier's GGN against ``torch.autograd.functional.hessian`` of a hand-written cross-entropy (the
+idea of the reference's ``tests/test_ggn.py:21-54``), a conv + BN + residual + stride-2 net written from the Flax
+definition with per-example ``jacrev`` and an explicit diag(p) - p p^T, and L L^T = diag(p) - p p^T.
 Unpinned by any reference fixture (stated here and in DESIGN.md): the eigenvalue clip of
 ``src/matfree_monkeypatch.py:19`` and the bidiagonalisation log-det of
 ``src/train_inducing.py:156-157`` — "parity unpinned" for those two.
