@@ -484,8 +484,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP prm) {
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
-template <int WM, int WN, int TM, int TN, bool SPLIT = false, bool PAR = false, bool BV = false>
+template <int WM, int WN, int TM, int TN, bool SPLIT = false, bool PAR = false, bool BV = false, bool KS = false>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP prm) {
+  static_assert(!KS || (!PAR && !SPLIT), "split-K: plain row order, exact f32");
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;
   constexpr int BE = T::BE;                                  // B floats per thread per K-tile (2, 4 or 8)
@@ -733,6 +734,27 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
   const unsigned dbg_lin = blockIdx.x + blockIdx.y * gridDim.x;
   const bool dbg_on = prm.dbg != nullptr && dbg_lin < 8192 && tid == 0;
   if (dbg_on) t_start = __builtin_amdgcn_s_memtime();
+  if (KS) {                               // this block's share of the K-tiles: [t0, t0 + ktiles)
+    const int z = (int)blockIdx.z, ks = (int)gridDim.z;
+    const int t0 = (int)((long long)ktiles * z / ks), t1 = (int)((long long)ktiles * (z + 1) / ks);
+    int t = t0;
+    while (seg < prm.nseg - 1 && t >= prm.seg[seg].Ktot / BK) { t -= prm.seg[seg].Ktot / BK; ++seg; }
+    begin_segment();
+    const int tpt = sC / BK, tap = t / tpt;
+    c0 = (t - tap * tpt) * BK; kh = tap / sKW; kw = tap - kh * sKW;
+    bbase += (long long)t * BK * N;
+    ktiles = t1 - t0;
+    set_tap();
+    pipelined_k_loop<AE, BE, ASZ, BSZ>(
+        ktiles, As, Bs, load_tile, store_tile, advance,
+        [&](const float* Asb, const float* Bsb) { mfma_sweep<WM, WN, TM, TN, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
+    IgemmP raw = prm;                       // raw sums: no epilogue operands, rows of this share's plane
+    raw.out = prm.partial + (long long)z * prm.partial_zs; raw.out_ps = (long long)prm.R * N;
+    raw.scale = nullptr; raw.e0 = nullptr; raw.e1 = nullptr; raw.xhat = nullptr; raw.res = nullptr; raw.dphi = nullptr;
+    raw.red0 = nullptr; raw.red1 = nullptr; raw.xhat2 = nullptr;
+    igemm_epilogue<WM, WN, TM, TN, false>(raw, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
+    return;
+  }
   if (!PAR || ktiles > 0) {               // PAR: a class no tap can reach (lone 1x1 stride-2) is all zeros
     begin_segment();
     set_tap();
@@ -755,6 +777,55 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_fast_kernel(const IgemmP p
     prm.dbg[3 * dbg_lin + 1] = t_loop_end;
     prm.dbg[3 * dbg_lin + 2] = t_end;
   }
+}
+
+// second pass of a split-K launch: the shares' raw sums back into the accumulator layout, then the fused epilogue
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_finish_kernel(const IgemmP prm, int ks) {
+  using T = Tile<WM, WN, TM, TN>;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN;
+  __shared__ float redbuf[2 * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int N = prm.N, R = prm.R;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tile_n = (int)blockIdx.x % tiles_n, tile_m = (int)blockIdx.x / tiles_n;
+  const int p = (int)blockIdx.y;
+  const int r0 = tile_m * BM, n0 = tile_n * BN;
+  for (int i = tid; i < 2 * BN; i += NT) redbuf[i] = 0.f;
+  f32x16 acc[TM][TN];
+  const float* __restrict__ part = prm.partial + (long long)p * R * N;
+  unsigned off[TM][TN][16];                // clamped element offsets: every load of a share is issued unconditionally
+  bool okk[TM][TN][16];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + (wn * TN + tn) * 32 + l31;
+      const int rbase = r0 + (wm * TM + tm) * 32 + 4 * lh;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = rbase + (reg & 3) + 8 * (reg >> 2);
+        okk[tm][tn][reg] = col < N && r < R;
+        off[tm][tn][reg] = okk[tm][tn][reg] ? (unsigned)(r * N + col) : 0u;
+        acc[tm][tn][reg] = 0.f;
+      }
+    }
+  for (int z = 0; z < ks; ++z) {           // one memory round trip per share: 16 TM TN independent loads in flight
+    const float* __restrict__ src = part + (long long)z * prm.partial_zs;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const float v = src[off[tm][tn][reg]];
+          acc[tm][tn][reg] += okk[tm][tn][reg] ? v : 0.f;
+        }
+  }
+  __syncthreads();
+  igemm_epilogue<WM, WN, TM, TN, false>(prm, acc, redbuf, p, r0, n0, wm, wn, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1511,6 +1582,8 @@ static bool igemm_fast_ok(const IgemmP& p) {
   return true;
 }
 
+static int cu_count();
+
 template <int WM, int WN, int TM, int TN>
 static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
   using T = Tile<WM, WN, TM, TN>;
@@ -1549,6 +1622,36 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       q.OW2 = p.OW / 2; q.OHW2 = (OH / 2) * q.OW2; q.Rc = (p.R / p.OHW) * q.OHW2;
       q.dOHW2 = FastDiv((unsigned)q.OHW2); q.dOW2 = FastDiv((unsigned)q.OW2);
       grid.x = (unsigned)(4ll * ((q.Rc + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN));
+    }
+    // few probes: fewer blocks than the chip holds and a long K loop — split the K-tiles over gridDim.z (each share
+    // >= 12 K-tiles, <= 4 shares; only where the chip is at most half full: at 200 blocks — the 64-column stage at one probe —
+    // the second pass costs more than the shorter K loop saves, 37 -> 40 us per launch), raw sums to a scratch plane per share, igemm_finish_kernel adds them
+    // and runs the fused epilogue (a fix-up inside the kernel by the share that arrives last at a tile counter needs
+    // agent-scope fences: 38 -> 80 us per launch, measured).  A/B switch LIP_NOKSPLIT.
+    if constexpr (WM == 2 && TM == 1 && TN == 1) {
+      static const bool noks = getenv("LIP_NOKSPLIT") != nullptr;
+      int kt = 0;
+      for (int s = 0; s < p.nseg; ++s) kt += p.seg[s].Ktot / BK;
+      const long long blocks = tiles * P;
+      long long ks = (4ll * cu_count()) / (blocks > 0 ? blocks : 1);
+      if (ks > kt / 12) ks = kt / 12;
+      if (ks > 4) ks = 4;
+      const size_t plane = (size_t)P * p.R * p.N;
+      if (!noks && !split && !par && !dbg && ks >= 2 && 2 * blocks <= cu_count() && plane * ks * sizeof(float) <= ((size_t)256 << 20)) {
+        static float* scratch = nullptr;          // one stream per process drives the engine: a single scratch suffices
+        static size_t cap = 0;
+        if (cap < plane * ks) {
+          if (scratch) { (void)hipStreamSynchronize(st); (void)hipFree(scratch); scratch = nullptr; cap = 0; }
+          if (hipMalloc((void**)&scratch, plane * ks * sizeof(float)) != hipSuccess) return hipErrorOutOfMemory;
+          cap = plane * ks;
+        }
+        q.partial = scratch; q.partial_zs = (long long)plane;
+        dim3 g3((unsigned)tiles, (unsigned)P, (unsigned)ks);
+        if (bv4) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false, true, true>), g3, dim3(T::NT), 0, st, q);
+        else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false, false, true>), g3, dim3(T::NT), 0, st, q);
+        hipLaunchKernelGGL((igemm_finish_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q, (int)ks);
+        return hipGetLastError();
+      }
     }
     if constexpr (WM == 4 && WN == 1) {
       // A operand straight into the MFMA registers (A/B switch LIP_NOADIRECT)
