@@ -211,6 +211,9 @@ __device__ __forceinline__ void pipelined_k_loop(int T, float* As, float* Bs, Lo
 // and issuing phase 0's loads before the K loop.
 // PAR: the block's rows are class-local indices of the parity class (ph, pw) (see IgemmP); `row_of` maps them back
 // to rows of the output tensor.
+#ifndef LIP_EPI_PHASE
+#define LIP_EPI_PHASE 8
+#endif
 template <int WM, int WN, int TM, int TN, bool PAR = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[TM][TN], float* redbuf, int p, int r0,
                                                int n0, int wm, int wn, int lane, int tid, int ph = 0, int pw = 0) {
@@ -231,6 +234,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
   const float* __restrict__ res = prm.res ? prm.res + (long long)p * prm.res_ps : nullptr;
   float* __restrict__ out = prm.out + (long long)p * prm.out_ps;
   const bool has_e1 = prm.e1 != nullptr, has_r1 = prm.red1 != nullptr;
+  constexpr int PH = LIP_EPI_PHASE;                   // accumulator rows drained per phase
+  const bool full_tile = (r0 + WM * TM * 32 <= R) && (n0 + BN <= N);      // uniform: no row / column of the block is masked
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int cl = (wn * TN + tn) * 32 + l31;
@@ -244,28 +249,65 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
     for (int tm = 0; tm < TM; ++tm) {
       const int rbase = r0 + (wm * TM + tm) * 32 + 4 * lh;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float xv[8], rv[8], dv[8], x2[8];
+      for (int h = 0; h < 16 / PH; ++h) {
+        // operand presence is uniform over the launch: ONE scalar branch per operand and phase around its eight loads,
+        // and one around the guarded / unguarded form of the eight stores (a per-element test of each pointer made the
+        // epilogue ~130 taken branches per 32 x 32 tile: 28 k cycles per block for a plain store, timeline study r2)
+        float xv[PH], rv[PH], dv[PH], x2[PH];
+        unsigned idx[PH];
+        bool ok[PH];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int reg = 8 * h + q;
+        for (int q = 0; q < PH; ++q) {
+          const int reg = PH * h + q;
           const int r = rbase + (reg & 3) + 8 * (reg >> 2);
-          const bool ok = cv && r < R;
-          const unsigned idx = ok ? (unsigned)(row_of(r) * N + col) : 0u;     // clamped: loads stay unconditional
-          xv[q] = has_e1 ? xhat[idx] : 0.f;
-          rv[q] = res ? res[idx] : 0.f;
-          dv[q] = dphi ? dphi[idx] : 1.f;
-          x2[q] = has_r1 ? xhat2[idx] : 0.f;
+          ok[q] = cv && r < R;
+          idx[q] = ok[q] ? (unsigned)(row_of(r) * N + col) : 0u;               // clamped: loads stay unconditional
         }
+        if (has_e1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int reg = 8 * h + q;
-          const int r = rbase + (reg & 3) + 8 * (reg >> 2);
-          if (cv && r < R) {
-            const float v = (acc[tm][tn][reg] * sc + e0v + e1v * xv[q] + rv[q]) * dv[q];
-            out[(unsigned)(row_of(r) * N + col)] = v;
+          for (int q = 0; q < PH; ++q) xv[q] = xhat[idx[q]];
+        } else {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) xv[q] = 0.f;
+        }
+        if (res) {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) rv[q] = res[idx[q]];
+        } else {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) rv[q] = 0.f;
+        }
+        if (dphi) {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) dv[q] = dphi[idx[q]];
+        } else {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) dv[q] = 1.f;
+        }
+        if (has_r1) {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) x2[q] = xhat2[idx[q]];
+        } else {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) x2[q] = 0.f;
+        }
+        if (full_tile) {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) {
+            const float v = (acc[tm][tn][PH * h + q] * sc + e0v + e1v * xv[q] + rv[q]) * dv[q];
+            out[idx[q]] = v;
             s0 += v;
             s1 += v * x2[q];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < PH; ++q) {
+            if (ok[q]) {
+              const float v = (acc[tm][tn][PH * h + q] * sc + e0v + e1v * xv[q] + rv[q]) * dv[q];
+              out[idx[q]] = v;
+              s0 += v;
+              s1 += v * x2[q];
+            }
           }
         }
       }
