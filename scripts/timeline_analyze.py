@@ -13,7 +13,7 @@ xcc = d[:, :, 5].astype(np.int64) & 0xf
 issue = d[:, :, 5].astype(np.int64) >> 8
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; se = (hw >> 13) & 7
 print(f"{f}: {d.shape[0]} blocks")
-for name, x in (("prologue (entry -> K loop)", t1 - t0), ("K loop", t2 - t1), ("epilogue issue", issue), ("epilogue total", t3 - t2), ("life", t3 - t0)):
+for name, x in (("prologue (entry -> K loop)", t1 - t0), ("K loop", t2 - t1), ("setup (entry -> first load issued)", issue), ("epilogue total", t3 - t2), ("life", t3 - t0)):
     x = x[:, 0]
     print(f"  {name:28s} mean {x.mean():8.0f}  median {np.median(x):8.0f}  p10 {np.percentile(x, 10):8.0f}  p90 {np.percentile(x, 90):8.0f} cycles")
 print(f"  K-tile period per wave: {(t2 - t1)[:, 0].mean() / ktiles:.0f} cycles ({8 * 64} of them MFMA)")
