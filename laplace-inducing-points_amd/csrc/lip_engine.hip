@@ -129,6 +129,7 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       if (op.OH <= 0 || op.OW <= 0) { set_error("IGEMM: bad geometry"); return LIP_ERR_ARG; }
       p.dOHW = FastDiv((unsigned)p.OHW); p.dOW = FastDiv((unsigned)p.OW);
       p.out = resolve(c, op.out); p.out_ps = op.out.pstride;
+      p.no_ksplit = op.out.space == LIP_SP_PRIM;
       p.scale = resolve(c, op.scale);
       p.e0 = resolve(c, op.e0); p.e0_ps = op.e0.pstride;
       p.e1 = resolve(c, op.e1); p.e1_ps = op.e1.pstride;

@@ -57,6 +57,8 @@ struct IgemmP {
   // split-K launches (few probes, under-filled grids): block z of gridDim.z accumulates its share of the K-tiles and
   // stores the raw sums to partial + z * partial_zs + p * R * N; igemm_finish_kernel adds the shares and runs the epilogue
   float* partial; long long partial_zs;
+  int no_ksplit;                        // outputs of the primal tape: ReLU gates / pooling arg-maxima are taken from these sums,
+                                        // so their summation order stays the one-block order whatever the launch geometry
   // parity-class row order of a stride-2 data gradient (fast kernel, OH and OW even): the rows of one block all
   // share (oh & 1, ow & 1), so the taps whose parity cannot match are skipped instead of gathered as zeros
   int Rc, OHW2, OW2;                    // rows per class n*(OH/2)*(OW/2), (OH/2)*(OW/2), OW/2

@@ -1679,7 +1679,7 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       if (ks > kt / 12) ks = kt / 12;
       if (ks > 4) ks = 4;
       const size_t plane = (size_t)P * p.R * p.N;
-      if (!noks && !split && !par && !dbg && ks >= 2 && 2 * blocks <= cu_count() && plane * ks * sizeof(float) <= ((size_t)256 << 20)) {
+      if (!noks && !p.no_ksplit && !split && !par && !dbg && ks >= 2 && 2 * blocks <= cu_count() && plane * ks * sizeof(float) <= ((size_t)256 << 20)) {
         static float* scratch = nullptr;          // one stream per process drives the engine: a single scratch suffices
         static size_t cap = 0;
         if (cap < plane * ks) {
