@@ -189,7 +189,8 @@ int lip_cg_direction(float* p, const float* r, const float* rr_new, const float*
 /* C (m, n) float64, overwritten = A B^T with A (m, K), B (n, K) float32 rows (row strides lda / ldb >= K, 4-byte
  * alignment suffices) accumulated in float64: the tall-skinny inner products whose float32 accumulation is too coarse —
  * the sampler's stiff-direction coefficients (src/sample.py:130-139 at cond 3e9), the Gram of Hutch++'s tall-skinny
- * orthonormalisation and its projections G Q^T (src/stochtrace.py:124-131).                              */
+ * orthonormalisation and its projections G Q^T (src/stochtrace.py:124-131).  Uses one partial-sum buffer per DEVICE:
+ * calls on different streams of one device must not overlap (the package issues them on one stream).          */
 int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64_t ldb, int32_t n, int64_t K, double* C,
                    void* stream);
 /* C (m, n) float32, overwritten = A B^T, same operand layout as lip_dot_nt_f64, float32 MFMA with the long reduction

@@ -22,6 +22,7 @@
 // dwords per half-wave: conflict-free ds_read_b32.
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 #include "lip_internal.h"
 
 namespace lip {
@@ -1626,6 +1627,34 @@ static bool igemm_fast_ok(const IgemmP& p) {
 
 static int cu_count();
 
+// Scratch planes of the split-K launches, one buffer per (device, stream) — kernels of one stream are ordered, so the
+// shares of launch i are consumed by its finishing pass before launch i+1 overwrites them; a second stream or device
+// gets its own buffer.  Grown on demand (after draining that stream), kept for the life of the process.  Returns null
+// when the table of 16 entries is full or the allocation fails (the caller reports out-of-memory).
+static float* ksplit_scratch(size_t floats, hipStream_t st) {
+  struct Entry { int dev; hipStream_t st; float* buf; size_t cap; };
+  static Entry table[16];
+  static int used = 0;
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* e = nullptr;
+  for (int i = 0; i < used; ++i)
+    if (table[i].dev == dev && table[i].st == st) { e = &table[i]; break; }
+  if (!e) {
+    if (used == 16) return nullptr;
+    e = &table[used++];
+    e->dev = dev; e->st = st; e->buf = nullptr; e->cap = 0;
+  }
+  if (e->cap < floats) {
+    if (e->buf) { (void)hipStreamSynchronize(st); (void)hipFree(e->buf); e->buf = nullptr; e->cap = 0; }
+    if (hipMalloc((void**)&e->buf, floats * sizeof(float)) != hipSuccess) return nullptr;
+    e->cap = floats;
+  }
+  return e->buf;
+}
+
 template <int WM, int WN, int TM, int TN>
 static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
   using T = Tile<WM, WN, TM, TN>;
@@ -1680,13 +1709,8 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       if (ks > 4) ks = 4;
       const size_t plane = (size_t)P * p.R * p.N;
       if (!noks && !p.no_ksplit && !split && !par && !dbg && ks >= 2 && 2 * blocks <= cu_count() && plane * ks * sizeof(float) <= ((size_t)256 << 20)) {
-        static float* scratch = nullptr;          // one stream per process drives the engine: a single scratch suffices
-        static size_t cap = 0;
-        if (cap < plane * ks) {
-          if (scratch) { (void)hipStreamSynchronize(st); (void)hipFree(scratch); scratch = nullptr; cap = 0; }
-          if (hipMalloc((void**)&scratch, plane * ks * sizeof(float)) != hipSuccess) return hipErrorOutOfMemory;
-          cap = plane * ks;
-        }
+        float* scratch = ksplit_scratch(plane * ks, st);      // per (device, stream): launches of one stream are ordered
+        if (!scratch) return hipErrorOutOfMemory;
         q.partial = scratch; q.partial_zs = (long long)plane;
         dim3 g3((unsigned)tiles, (unsigned)P, (unsigned)ks);
         if (bv4) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false, true, true>), g3, dim3(T::NT), 0, st, q);
