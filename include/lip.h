@@ -119,6 +119,10 @@ int lip_sizeof_op(void);                   /* sizeof(lip_op_t): lets the ctypes 
  *     ("bf16x3": ~1e-5 relative error per product, ~5x fewer matrix-pipe cycles).                     */
 int lip_set_precision(int32_t mode);
 int lip_get_precision(void);
+/* split-K implicit GEMM of under-filled launches (few probes): 1 = on (default), 0 = off.  The
+ * results differ only in the summation order of the K axis; the switch exists so that a test can compare the two
+ * orders in one process (the environment variable LIP_NOKSPLIT is read once).                          */
+int lip_set_split_k(int32_t on);
 
 /* ---- engine: one per (network, theta_MAP, data slice Z) binding on one device --------
  * Replaces the closure factories compute_ggn_vp / compute_W_vps (src/ggn.py:97,9): they

@@ -56,6 +56,7 @@ SIGNATURES = {
     "lip_last_error": (C.c_char_p, []),
     "lip_sizeof_op": (C.c_int, []),
     "lip_set_precision": (C.c_int, [C.c_int32]),
+    "lip_set_split_k": (C.c_int, [C.c_int32]),
     "lip_get_precision": (C.c_int, []),
     "lip_engine_create": (C.c_int, [C.POINTER(_V), C.c_int64, C.c_int32, C.c_int32]),
     "lip_engine_destroy": (C.c_int, [_V]),

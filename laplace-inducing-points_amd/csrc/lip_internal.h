@@ -145,6 +145,7 @@ hipError_t launch_scale_copy(float* y, const float* x, float a, long long count,
 void set_error(const char* fmt, ...);
 int precision_mode();
 void set_precision_mode(int m);
+void set_split_k_mode(int on);
 
 // ---- wave / block reductions (wave = 64 lanes on gfx950) --------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1616,6 +1616,14 @@ int precision_mode() {
 }
 void set_precision_mode(int m) { g_precision = m ? 1 : 0; }
 
+// split-K of under-filled implicit GEMMs: -1 = not set (environment LIP_NOKSPLIT decides), 0 = off, 1 = on
+static int g_split_k = -1;
+void set_split_k_mode(int on) { g_split_k = on ? 1 : 0; }
+static bool split_k_enabled() {
+  if (g_split_k < 0) g_split_k = getenv("LIP_NOKSPLIT") ? 0 : 1;
+  return g_split_k == 1;
+}
+
 static bool igemm_fast_ok(const IgemmP& p) {
   for (int s = 0; s < p.nseg; ++s) {
     const SegP& q = p.seg[s];
@@ -1700,7 +1708,7 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
     // and runs the fused epilogue (a fix-up inside the kernel by the share that arrives last at a tile counter needs
     // agent-scope fences: 38 -> 80 us per launch, measured).  A/B switch LIP_NOKSPLIT.
     if constexpr (WM == 2 && TM == 1 && TN == 1) {
-      static const bool noks = getenv("LIP_NOKSPLIT") != nullptr;
+      const bool noks = !split_k_enabled();
       int kt = 0;
       for (int s = 0; s < p.nseg; ++s) kt += p.seg[s].Ktot / BK;
       const long long blocks = tiles * P;
