@@ -1253,9 +1253,15 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_kernel(const WgradP prm) {
 template <int WM, int WN, int TM, int TN, bool PB = false, bool BV4 = PB, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP prm) {
   using T = Tile<WM, WN, TM, TN>;
-  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN;
+  // A quads (four channels of one row) of a K-tile over the threads: quad q = tid + j NT -> (row q / QPR, m-quad q % QPR).
+  // When NT is a multiple of the quads per row every thread keeps ONE m-quad (the original mapping); the four-wave
+  // 96-row tile <1,4,3,1> has 384 quads on 256 threads: two quads per thread, the second only for tid < 128 (AGEN)
+  constexpr int QTOT = BM * BK / 4, AQ = (QTOT + NT - 1) / NT, AE = 4 * AQ;
+  constexpr bool AGEN = (NT % (BM / 4)) != 0 || (QTOT % NT) != 0;
+  static_assert(!SPLIT || !AGEN, "split precision keeps the one-m-quad-per-thread mapping");
   static_assert(!PB || BV4, "the probe-batched variant reads the cotangent as float4");
-  static_assert(!SPLIT || (BV4 && T::AQ == 2), "split precision: float4 cotangent rows, two A quads per thread");
+  static_assert(!SPLIT || (BV4 && AQ == 2), "split precision: float4 cotangent rows, two A quads per thread");
   // SPLIT (bf16x3): both operands are k-contiguous bf16 rows ([m][16 k], [n][16 k]; hi and lo planes), but global
   // memory runs along m resp. n at fixed r — each thread therefore owns the row PAIR (2 kp, 2 kp + 1) of its four
   // channels and stores k-adjacent pairs (one ds_write_b32 per channel and plane).
@@ -1310,19 +1316,27 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-  // this thread's m (fixed): m = m0 + 4*(tid % QPR) -> tap (kh, kw) and channel ci
-  const int my_m = m0 + 4 * (tid % QPR);
-  const bool mvalid = my_m < M;
-  int thh = 0, tww = 0, ci = 0;
-  if (mvalid) {
-    const int tap = my_m / prm.C;
-    ci = my_m - tap * prm.C;
-    const int kh = tap / prm.KW, kw = tap - kh * prm.KW;
-    thh = kh - prm.pad_h;
-    tww = kw - prm.pad_w;
+  // quad j of this thread: m = m0 + 4 * (q % QPR) -> tap (kh, kw) and channel ci; row q / QPR of the K-step.  Without
+  // AGEN all AQ quads share the m-quad (the compiler folds the copies), rows krow0 + j * NT / QPR
+  bool mvalid[AQ];
+  int thh[AQ], tww[AQ], ci[AQ], krow[AQ];
+#pragma unroll
+  for (int j = 0; j < AQ; ++j) {
+    const int q = tid + j * NT;
+    const int kq = q / QPR, mq = q - kq * QPR;
+    const int my_m = m0 + 4 * mq;
+    mvalid[j] = my_m < M && (!AGEN || q < QTOT);
+    thh[j] = 0; tww[j] = 0; ci[j] = 0;
+    krow[j] = SPLIT ? 2 * (tid / QPR) + j : kq;
+    if (mvalid[j]) {
+      const int tap = my_m / prm.C;
+      ci[j] = my_m - tap * prm.C;
+      const int kh = tap / prm.KW, kw = tap - kh * prm.KW;
+      thh[j] = kh - prm.pad_h;
+      tww[j] = kw - prm.pad_w;
+    }
   }
-  const int krow0 = SPLIT ? 2 * (tid / QPR) : tid / QPR;   // row of quad j inside the K-step: krow0 + j*(NT/QPR); SPLIT: krow0 + j
-  constexpr int KSTEP = SPLIT ? 1 : NT / QPR;
+  const int krow0 = SPLIT ? 2 * (tid / QPR) : tid / QPR;   // SPLIT: first row of this thread's row pair
   constexpr int NB = SPLIT ? BU : (BV4 ? BQ : BE);   // B units (SPLIT: 2 rows x 4 channels) / load instructions per thread
   unsigned bidx[NB];
   int bk[NB];
@@ -1357,12 +1371,12 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
   auto load_tile = [&](float (&areg)[AE], float (&breg)[BE]) {
 #pragma unroll
     for (int j = 0; j < AQ; ++j) {
-      const int r = rk0 + krow0 + j * KSTEP;
+      const int r = rk0 + krow[j];
       const int i = prm.dOHW.div(r), rem = r - i * OHW;
       const int oh = prm.dOW.div(rem), ow = rem - oh * OW;
-      const int ih = oh * stride + thh, iw = ow * stride + tww;
-      const bool ok = mvalid && (r < rend) && ((unsigned)ih < (unsigned)IH) && ((unsigned)iw < (unsigned)IW);
-      const float* src = ok ? (prm.a + (unsigned)(((i * IH + ih) * IW + iw) * C + ci)) : prm.zeros;
+      const int ih = oh * stride + thh[j], iw = ow * stride + tww[j];
+      const bool ok = mvalid[j] && (r < rend) && ((unsigned)ih < (unsigned)IH) && ((unsigned)iw < (unsigned)IW);
+      const float* src = ok ? (prm.a + (unsigned)(((i * IH + ih) * IW + iw) * C + ci[j])) : prm.zeros;
       const float4 v = *reinterpret_cast<const float4*>(src);
       areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
     }
@@ -1407,8 +1421,9 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
     for (int j = 0; j < AQ; ++j) {
       const int q = tid + j * NT;
       const int k = q / QPR, mq = q - k * QPR;
-      *reinterpret_cast<float4*>(&Asb[k * LDA + 4 * mq]) =
-          make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
+      if (!AGEN || q < QTOT)
+        *reinterpret_cast<float4*>(&Asb[k * LDA + 4 * mq]) =
+            make_float4(areg[4 * j + 0], areg[4 * j + 1], areg[4 * j + 2], areg[4 * j + 3]);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -1893,8 +1908,13 @@ static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
     q.ksplit = ks < 1 ? 1 : (int)ks;
   }
   dim3 grid((unsigned)tiles, 1, (unsigned)q.ksplit);
-  if (precision_mode() == 1) hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(T::NT), 0, st, q);
-  else hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
+  if constexpr (T::NT % (T::BM / 4) == 0) {        // (the split-precision loader needs one m-quad per thread)
+    if (precision_mode() == 1) {
+      hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(T::NT), 0, st, q);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, true>), grid, dim3(T::NT), 0, st, q);
   return hipGetLastError();
 }
 
@@ -1905,8 +1925,16 @@ hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
   // measured on MI355X (CIFAR ResNet1M, P = 256): N = 32, M = 288: 3.72 -> 2.67 ms; N = 64, M = 288: 1.58 -> 1.36 ms;
   // N = 64, M = 576 (11% padded rows with 128-row tiles): 2.61 -> 2.68 ms, so that case stays per-probe
   const int waste128 = (p.M + 127) / 128 * 128 - p.M;
-  if (pb_ok && (p.N <= 32 || 5 * waste128 >= p.M))
-    return (p.M % 96 == 0 && p.M % 128 != 0) ? run_wgrad_pb<3, 1, 1, 4>(p, P, st) : run_wgrad_pb<2, 2, 2, 2>(p, P, st);
+  static const bool pb96 = getenv("LIP_NOPB96") == nullptr;     // A/B: 96-row probe-batched tile also for N = 64, M = 576
+  if (pb_ok && (p.N <= 32 || 5 * waste128 >= p.M || (pb96 && p.M % 96 == 0 && p.M % 128 != 0))) {
+    // 96-row tiles for M = 288 / 576: four waves side by side along the probes' columns (each wave 96 x 32 = one
+    // probe's channels) — the three-wave form <3,1,1,4> (272 registers, one block per CU) left the fourth SIMD of
+    // every CU idle; it stays for the split-precision mode, whose row-pair loader needs one m-quad per thread
+    static const bool w3 = getenv("LIP_WGRAD3") != nullptr;          // A/B switch
+    if (p.M % 96 == 0 && p.M % 128 != 0)
+      return (precision_mode() == 1 || w3) ? run_wgrad_pb<3, 1, 1, 4>(p, P, st) : run_wgrad_pb<1, 4, 3, 1>(p, P, st);
+    return run_wgrad_pb<2, 2, 2, 2>(p, P, st);
+  }
   // (64-row per-probe tiles for M = 288 were measured slower than 128-row ones: 54.6 vs 52.4 ms per step — removed)
   const bool small_m = p.M <= 64;
   if (p.N > 64) return small_m ? run_wgrad<2, 2, 1, 2>(p, P, st) : run_wgrad<2, 2, 2, 2>(p, P, st);
