@@ -210,6 +210,20 @@ def main():
     value = P * args.steps / dt                    # products over the WHOLE n_total-example set per second
     per_shard = value * world                      # products counted per 50-example shard (round-1 unit)
 
+    # N > 1, secondary figure: the OTHER sharding north_star names — Hutchinson probes sharded, no data-path collective:
+    # every rank sweeps its own block of P probes over a full 50-example set (the trace estimator then all-reduces P
+    # scalars per rank, dist.sharded_hutchinson).  N * P products per step, each over a 50-example set.
+    probe_sharded = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.ggn_vp(V, full / n, alpha)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        probe_sharded = P * world * args.steps / float(t.item())
+
     # ---- live per-kernel figure: HIP events on the launch stream, instrumented extra steps -------------
     eng.profile(True)
     prof_steps = max(1, min(3, args.steps))
@@ -607,12 +621,15 @@ def main():
 
     if rank == 0:
         line = dict(metric="GGN-vector products/sec", value=value, example_probe_products_per_s=value * n_total,
-                    per_shard_products_per_s=per_shard, unit="GGN-vp/s", n_gpus=world, steps=args.steps,
+                    per_shard_products_per_s=per_shard, probe_sharded_products_per_s=probe_sharded,
+                    unit="GGN-vp/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
                     scaling_note="weak scaling in the DATA sum: per-GPU work is fixed (50 examples x P probes), the data set "
                                  "grows with N, so `value` (products over the whole set per second) stays flat when scaling "
                                  "is perfect — it is step time that should stay constant; the throughput that grows with N "
-                                 "is example_probe_products_per_s (= value x 50 N)",
+                                 "is example_probe_products_per_s (= value x 50 N); probe_sharded_products_per_s is the "
+                                 "other sharding of north_star, measured in the same run when N > 1: every rank sweeps its own P "
+                                 "probes over a 50-example set, no data-path collective (N P products per step)",
                     vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload="CIFAR-CNN ResNet1M GGN-vp (BASELINE configs[3]): D=1084586, "
                                          f"n={n} examples/GPU, P={P} Rademacher probes/block, alpha=0.005, "
