@@ -1928,8 +1928,8 @@ hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
   static const bool pb96 = getenv("LIP_NOPB96") == nullptr;     // A/B: 96-row probe-batched tile also for N = 64, M = 576
   if (pb_ok && (p.N <= 32 || 5 * waste128 >= p.M || (pb96 && p.M % 96 == 0 && p.M % 128 != 0))) {
     // 96-row tiles for M = 288 / 576: four waves side by side along the probes' columns (each wave 96 x 32 = one
-    // probe's channels) — the three-wave form <3,1,1,4> (272 registers, one block per CU) left the fourth SIMD of
-    // every CU idle; it stays for the split-precision mode, whose row-pair loader needs one m-quad per thread
+    // probe's channels) — the three-wave form <3,1,1,4> (208 registers: two blocks of three waves per CU) put 2-2-1-1
+    // waves on the four SIMDs; it stays for the split-precision mode, whose row-pair loader needs one m-quad per thread
     static const bool w3 = getenv("LIP_WGRAD3") != nullptr;          // A/B switch
     if (p.M % 96 == 0 && p.M % 128 != 0)
       return (precision_mode() == 1 || w3) ? run_wgrad_pb<3, 1, 1, 4>(p, P, st) : run_wgrad_pb<1, 4, 3, 1>(p, P, st);
