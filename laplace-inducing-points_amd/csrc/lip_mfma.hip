@@ -212,6 +212,13 @@ __device__ __forceinline__ void pipelined_k_loop(int T, float* As, float* Bs, Lo
 // and issuing phase 0's loads before the K loop.
 // PAR: the block's rows are class-local indices of the parity class (ph, pw) (see IgemmP); `row_of` maps them back
 // to rows of the output tensor.
+// This translation unit is built with -fno-slp-vectorize (Makefile): with the SLP vectoriser on, the two-phase form
+// (PH = 8) of igemm_fast_kernel<4,1,1,2,SPLIT> — the 64-column tile of the bf16x3 mode — returned a wrong and
+// run-to-run different red1 (sum of v * x-hat, the BN-scale cotangent) while `out` and red0 were right: 3e-4 of the
+// GGN-vp at the bench geometry (round-2 record).  Localised op by op with scripts/split_localise.py / split_detail.py;
+// not the LDS reduction (direct global atomics: same), not the waits (s_waitcnt 0 before the compute: same), not the
+// scheduler strategy; PH = 4 or 16, or SLP off, give 4.5e-6 and reproducible sums.  Packed-f32 code (v_pk_mul/add/fma,
+// v_pk_mov with op_sel) is what the vectoriser adds; f32 throughput is unchanged without it (1706 vs 1703 GGN-vp/s).
 #ifndef LIP_EPI_PHASE
 #define LIP_EPI_PHASE 8
 #endif

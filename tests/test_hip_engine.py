@@ -199,3 +199,36 @@ def test_split_precision_mode_accuracy():
         set_precision("f32")
     assert e32 < 2e-6 and e16 < 5e-5, (e32, e16)
 
+
+
+def test_split_precision_at_the_bench_geometry():
+    """bf16x3 mode on the binding bench.py runs (ResNet1M 32x32, n = 50, P = 32: the 128-row implicit-GEMM tiles and the
+    probe-batched weight gradients are selected, as at P = 256).  Round 2's record showed 3e-4 and run-to-run different
+    results there (the BN-scale cotangent reduced in the epilogue of the 64-column tile, see igemm_epilogue); the small
+    test above never selects those kernels.  Stated tolerance: 5e-5 * max|ref| against the float64 oracle for the
+    split mode (measured 5e-6), 2e-5 for exact f32; two split runs agree to atomics-reordering level (1e-6)."""
+    from lip_amd import krylov
+    from lip_amd.engine import set_precision
+    from oracle import ggn as og
+    net = ResNet1M(10)
+    st64 = create_state(net, 1231231234, dtype=F64)
+    Z = torch.rand(50, 32, 32, 3, dtype=F64, generator=torch.Generator().manual_seed(280300))
+    P, scale, alpha = 32, 980.0, 0.005
+    eng = LinearizedNet(st64, Z, "classifier", workspace_bytes=4 << 30, max_chunk=P)
+    assert eng.chunk == P
+    V = krylov.fill_rademacher(P, eng.D, 1234, "cuda")
+    ref_vp = og.compute_ggn_vp_batched(st64, Z, "classifier", full_set_size=49000)
+    ref = torch.stack([ref_vp(v) + alpha * v for v in V[:2].double().cpu()])
+    try:
+        Y32 = eng.ggn_vp(V, scale, alpha).clone()
+        set_precision("bf16x3")
+        Ya = eng.ggn_vp(V, scale, alpha).clone()
+        Yb = eng.ggn_vp(V, scale, alpha).clone()
+    finally:
+        set_precision("f32")
+    torch.cuda.synchronize()
+    m = Y32.abs().max().item()
+    e32, e16 = _rel(Y32[:2], ref), _rel(Ya[:2], ref)
+    rr = (Ya - Yb).abs().max().item() / m
+    d = (Ya - Y32).abs().max().item() / m
+    assert e32 < 2e-5 and e16 < 5e-5 and rr < 1e-6 and d < 5e-5, (e32, e16, rr, d)
