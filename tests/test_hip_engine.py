@@ -205,8 +205,11 @@ def test_split_precision_at_the_bench_geometry():
     """bf16x3 mode on the binding bench.py runs (ResNet1M 32x32, n = 50, P = 32: the 128-row implicit-GEMM tiles and the
     probe-batched weight gradients are selected, as at P = 256).  Round 2's record showed 3e-4 and run-to-run different
     results there (the BN-scale cotangent reduced in the epilogue of the 64-column tile, see igemm_epilogue); the small
-    test above never selects those kernels.  Stated tolerance: 5e-5 * max|ref| against the float64 oracle for the
-    split mode (measured 5e-6), 2e-5 for exact f32; two split runs agree to atomics-reordering level (1e-6)."""
+    test above never selects those kernels.  Stated tolerances: against the float64 oracle both modes stay inside the
+    repo's fp32 bound 2e-4 * max|ref| (measured 6.2e-5 for exact f32 — float32 parameters and inputs at this depth —
+    and 6.5e-5 for bf16x3); what the split operands ADD is bounded over all 32 probes by 2e-5 * max|Y| against the f32
+    sweep on the same binding (measured 6.6e-6; 3e-4 before the fix); two split runs agree to atomics-reordering
+    level, 1e-6 (measured 5e-8; 2.5e-4 before the fix)."""
     from lip_amd import krylov
     from lip_amd.engine import set_precision
     from oracle import ggn as og
@@ -231,4 +234,4 @@ def test_split_precision_at_the_bench_geometry():
     e32, e16 = _rel(Y32[:2], ref), _rel(Ya[:2], ref)
     rr = (Ya - Yb).abs().max().item() / m
     d = (Ya - Y32).abs().max().item() / m
-    assert e32 < 2e-5 and e16 < 5e-5 and rr < 1e-6 and d < 5e-5, (e32, e16, rr, d)
+    assert e32 < 2e-4 and e16 < 2e-4 and rr < 1e-6 and d < 2e-5, (e32, e16, rr, d)
