@@ -115,20 +115,30 @@ def rows_combine(Cm: torch.Tensor, Y: torch.Tensor, Z: Optional[torch.Tensor] = 
     return O
 
 
-def gram_orthonormalize(Y: torch.Tensor, rtol: float = 1e-10, passes: int = 2) -> torch.Tensor:
+def gram_orthonormalize(Y: torch.Tensor, rtol: float = 1e-10, passes: int = 2, return_transform: bool = False):
     """Orthonormal rows spanning the rows of Y (s, N), N >> s, without a Householder QR of a tall matrix: the float64
     Gram G = Y Y^T (``dot_nt``: one read of Y), its s x s eigendecomposition G = U L U^T, Q = L^(-1/2) U^T Y
     (``rows_combine``: one read + one write) — CholeskyQR with the Cholesky factor where it exists and the symmetric
     factor L^(1/2) U^T otherwise, so a rank-deficient Y (Hutch++ with more probes than dimensions,
     ``tests/test_stochtrace.py:90-97``) simply yields fewer rows.  Done twice ("CholeskyQR2"): the first pass leaves ||Q Q^T - I|| ~ eps cond(Y)^2,
     the second brings it to rounding.  12 N s bytes per pass (>= 3 * 4 * D * s).  Replaces
-    ``jnp.linalg.qr`` at ``src/stochtrace.py:128`` (only span(Q) enters the estimator)."""
+    ``jnp.linalg.qr`` at ``src/stochtrace.py:128`` (only span(Q) enters the estimator).  ``return_transform`` also
+    returns the (r, s) float64 matrix T with Q = T Y (the adjoint of the orthonormalisation needs it,
+    ``stochastic_grad.py``)."""
     s_rows, N = Y.shape
+    if s_rows == 0 or not bool((Y != 0).any()):
+        # rank 0 (a zero operator output): the reference's QR simply proceeds with nothing to deflate
+        Q0 = torch.zeros(0, N, device=Y.device, dtype=torch.float32)
+        return (Q0, torch.zeros(0, s_rows, device=Y.device, dtype=torch.float64)) if return_transform else Q0
     if s_rows > 384 or N < 4 * s_rows:
         # not tall-skinny (the reference's own "more probes than dimensions" test): Householder QR in float64
-        Qf, _ = torch.linalg.qr(Y.T.double(), mode="reduced")
+        Qf, Rf = torch.linalg.qr(Y.T.double(), mode="reduced")
+        if return_transform:                        # Q = R^-T Y (full column rank assumed on this path)
+            Tm = torch.linalg.solve_triangular(Rf.T, torch.eye(Rf.shape[0], device=Y.device, dtype=torch.float64), upper=False)
+            return Qf.T.float().contiguous(), Tm
         return Qf.T.float().contiguous()
     Q = Y
+    Ttot = None                                     # running transform: Q = Ttot Y
     for it in range(passes):
         G = dot_nt(Q, Q)
         G = 0.5 * (G + G.T)
@@ -147,7 +157,8 @@ def gram_orthonormalize(Y: torch.Tensor, rtol: float = 1e-10, passes: int = 2) -
             keep = ev > (rtol if it == 0 else 0.25) * ev.max().clamp_min(1e-300)
             Cm = (U[:, keep] * torch.rsqrt(ev[keep])).T
         Q = rows_combine(Cm, Q)
-    return Q
+        Ttot = Cm if Ttot is None else Cm @ Ttot
+    return (Q, Ttot) if return_transform else Q
 
 
 def lanczos_tridiag(matvec: Callable[[torch.Tensor], torch.Tensor], V0: torch.Tensor, k: int
@@ -349,11 +360,12 @@ def _cgs2(lib, Qbuf, ldq, w, P, j, k, N, c1, c2, nrm2, st):
                  "lip_multi_axpy_norm")
 
 
-def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: int):
+def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: int, return_bases: bool = False):
     """k-step Golub-Kahan bidiagonalisation with full re-orthogonalisation, P recurrences at once, started in
     the domain: A V = U B with B (k, k) upper bidiagonal (matfree ``decomp.bidiag`` as the reference calls it,
     ``src/train_inducing.py:156``).  ``matvec``: (P, N) -> (P, n_out); ``vecmat``: (P, n_out) -> (P, N).
-    Returns (alphas (P, k), betas (P, k-1))."""
+    Returns (alphas (P, k), betas (P, k-1)) and, with ``return_bases``, the bases V (P, k, N) and U (P, k, n_out)
+    (views of the padded storage) that the adjoint recurrence of ``stochastic_grad.py`` walks back over."""
     lib = nv.load()
     P, N = _chk(V0).shape
     st = nv.stream_ptr()
@@ -380,6 +392,8 @@ def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: 
             _cgs2(lib, Vb, ldv, w, P, j + 1, k, N, c1, c2, nrm2, st)
             betas[:, j] = torch.sqrt(nrm2)
             nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(nrm2), nv.ptr(Vb), j + 1, P, k, N, ldv, st), "lip_scale_store")
+    if return_bases:
+        return alphas, betas, Vb[:, :, :N], Ub[:, :, :n_out]
     return alphas, betas
 
 

@@ -1,0 +1,282 @@
+"""Matrix-free gradient of the reference's STOCHASTIC inducing-point objective
+(``jax.value_and_grad(alternative_objective_scalable)``, ``/root/reference/src/train_inducing.py:87-173,195-196``).
+
+The objective is  F(Z) = hutchpp_v2(C; probes) + mean_p SLQ_k(p),  C = S S_z^-1  with
+
+    S      = alpha I + (N/K_b) GGN(X)                         data precision (does not depend on Z)
+    S_z^-1 = alpha^-1 I - alpha^-2 W M^-1 W^T =: B            Woodbury, M = beta^-1 I + alpha^-1 W^T W   (``:127-132``)
+    SLQ_k  = ||p||^2 e1^T log(B_k^T B_k) e1,  B_k the Golub-Kahan bidiagonal of  v -> [sqrt(alpha) v ; s_b W^T v]  (``:156-169``)
+
+and it depends on Z only through the factor W = W(Z) (D x d, d = M K; column (j, k) = c J(z_j)^T L(z_j) e_k).  Reverse
+mode through the two estimators therefore ends in a cotangent of W that is a sum of rank-one terms,
+
+    dF = sum_t u_t^T dW x_t ,        u_t in R^D,  x_t in R^d ,
+
+one or two per operator application of the forward pass, and the gradient is that of the PAIRING
+sum_t sum_j < J(z_j) u_t , c L(z_j) x_tj >  with (u_t, x_t) frozen — the second-order pass of ``second_order.py`` with the
+directions shared by the examples.  No factor of the data batch (K rows of D floats per image) is formed: X enters
+only through products with S, twice as many as the value alone needs.
+
+Hutch++ (``src/stochtrace.py:118-135``).  With Q an orthonormal basis of range(Y), Y = C S_1^T, the estimator is a
+function of C and of the projector Pi = Q Q^T only,  T = tr(C Pi) + (1/s2) tr(G (I - Pi) C (I - Pi) G^T), so its
+gradient does not depend on which QR produced Q (the reference's Householder QR, ``:128``, or the CholeskyQR2 of
+``krylov.gram_orthonormalize``).  dPi = (I - Pi) dY Y^+ + transpose gives, in row form (rows = vectors),
+
+    Ybar = Cm^T [ E_perp - (1/s2) ( (H Q^T)^T G_perp + (G Q^T)^T H_perp ) ],   E = (C + C^T) Q,  H = (C + C^T) G_perp,
+
+(Q = Cm Y; _perp = rows projected off range(Q)) and the cotangent of C is  sum_i ybar_i s_i^T + sum_i q_i q_i^T +
+(1/s2) sum_r g_r g_r^T  (g_r the projected probes).  For C = S B, a term a b^T of Cbar contributes
+
+    -alpha^-1 [ (B S a) (M^-1 W^T b)^T + (B b) (M^-1 W^T S a)^T ]
+
+to the cotangent of W (the dependence of M^-1 on W^T W included) — every vector on the left already exists in the
+forward / adjoint pass.
+
+SLQ.  Full re-orthogonalisation is the identity in exact arithmetic for EVERY operator, so the estimator is the same
+function of W as the plain Golub-Kahan recurrence  alpha_j u_j = A v_j - beta_{j-1} u_{j-1},  beta_j v_{j+1} = A^T u_j -
+alpha_j v_j, and reverse mode runs over that recurrence with the (re-orthogonalised) stored bases: one application of A
+and one of A^T per step, two rank-one terms per step.
+
+The D-sized linear algebra is behind a small vector backend: :class:`HipVec` (``lip_dot_nt_f64``, ``lip_rows_combine``,
+``lip_bdot``, ``lip_axpby`` — the product path) and :class:`TorchVec` (plain torch, any dtype / device: used by the CPU
+tests of the host logic against reverse mode through the oracle).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# vector backends
+# ----------------------------------------------------------------------------------------------------------------
+class TorchVec:
+    """Plain torch algebra on (rows, N) blocks (tests of the host logic; float64 on the CPU)."""
+
+    def gram(self, A, B):                                   # A B^T, float64
+        return A.double() @ B.double().T
+
+    def combine(self, C, Y, Z=None, zscale=0.0):            # C Y + zscale Z
+        out = C.to(Y.dtype) @ Y
+        return out if Z is None else out + zscale * Z
+
+    def bdot(self, X, Y):                                   # row-wise <x, y>, float64
+        return (X.double() * Y.double()).sum(1)
+
+    def lin(self, terms):                                   # sum_i coef_i[:, None] * block_i ; coef (P,) or scalar
+        out = None
+        for c, X in terms:
+            c = c if not torch.is_tensor(c) else c.to(X.dtype)[:, None]
+            out = c * X if out is None else out + c * X
+        return out
+
+    def orth(self, Y):                                      # Q (r, N) orthonormal rows, Cm with Q = Cm Y
+        Qc, R = torch.linalg.qr(Y.T, mode="reduced")        # Y^T = Qc R  ->  Q = R^-T Y
+        Cm = torch.linalg.solve_triangular(R.T, torch.eye(R.shape[0], dtype=Y.dtype, device=Y.device), upper=False)
+        return Qc.T.contiguous(), Cm.double()
+
+    def bidiag(self, matvec, vecmat, V0, k, n_out):
+        """Golub-Kahan with full re-orthogonalisation, P recurrences at once: (alphas, betas, V (P,k,N), U (P,k,n_out))."""
+        P, N = V0.shape
+        V = torch.zeros(P, k, N, dtype=V0.dtype, device=V0.device)
+        U = torch.zeros(P, k, n_out, dtype=V0.dtype, device=V0.device)
+        al = torch.zeros(P, k, dtype=V0.dtype, device=V0.device)
+        be = torch.zeros(P, max(k - 1, 0), dtype=V0.dtype, device=V0.device)
+        v = V0 / V0.norm(dim=1, keepdim=True)
+        for j in range(k):
+            V[:, j] = v
+            u = matvec(v)
+            for _ in range(2):
+                u = u - torch.einsum("pk,pkn->pn", torch.einsum("pkn,pn->pk", U[:, :j], u), U[:, :j])
+            al[:, j] = u.norm(dim=1)
+            u = u / al[:, j, None]
+            U[:, j] = u
+            if j + 1 < k:
+                w = vecmat(u)
+                for _ in range(2):
+                    w = w - torch.einsum("pk,pkn->pn", torch.einsum("pkn,pn->pk", V[:, :j + 1], w), V[:, :j + 1])
+                be[:, j] = w.norm(dim=1)
+                v = w / be[:, j, None]
+        return al, be, V, U
+
+
+class HipVec:
+    """The product backend: every D-sized operation is a kernel of ``csrc/lip_krylov.hip``."""
+
+    def __init__(self):
+        from . import krylov
+        self.k = krylov
+
+    def gram(self, A, B):
+        return self.k.dot_nt(A.contiguous(), B.contiguous())
+
+    def combine(self, C, Y, Z=None, zscale=0.0):
+        return self.k.rows_combine(C, Y.contiguous(), None if Z is None else Z.contiguous(), zscale)
+
+    def bdot(self, X, Y):
+        return self.k.bdot(X.contiguous(), Y.contiguous()).double()
+
+    def lin(self, terms):
+        (c0, X0), rest = terms[0], terms[1:]
+        P = X0.shape[0]
+        dev = X0.device
+
+        def coef(c):
+            return c.to(device=dev, dtype=torch.float32).contiguous() if torch.is_tensor(c) else torch.full((P,), float(c), device=dev)
+
+        out = X0.contiguous().clone()
+        zero = torch.zeros(P, device=dev)
+        self.k.axpby(out, out, zero, 1.0, coef(c0), 1.0)                     # out = c0 * X0
+        one = torch.ones(P, device=dev)
+        for c, X in rest:
+            self.k.axpby(out, X.contiguous(), coef(c), 1.0, one, 1.0)        # out += c * X
+        return out
+
+    def orth(self, Y):
+        return self.k.gram_orthonormalize(Y.contiguous(), return_transform=True)
+
+    def bidiag(self, matvec, vecmat, V0, k, n_out):
+        return self.k.bidiag(matvec, vecmat, V0.contiguous(), k, n_out, return_bases=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Hutch++ on C = S B: value and cotangent of W
+# ----------------------------------------------------------------------------------------------------------------
+def _hutchpp_value_and_terms(S_rows, WT_rows, W_rows, Minv, alpha, probes, s1, s2, vec):
+    a_inv = 1.0 / alpha
+
+    def B(V):                                   # S_z^-1 on rows (Woodbury, :127-132); also x = M^-1 W^T v
+        x = WT_rows(V).double() @ Minv
+        return vec.lin([(a_inv, V), (-a_inv * a_inv, W_rows(x.to(V.dtype)))]), x
+
+    Sp, G = probes[:s1], probes[s1:s1 + s2]
+    # ---- forward (src/stochtrace.py:118-135)
+    BS, xS = B(Sp)
+    Y = S_rows(BS)
+    Q, Cm = vec.orth(Y)                         # Q = Cm Y, orthonormal rows
+    r = Q.shape[0]
+    BQ, xQ = B(Q)
+    CQ = S_rows(BQ)
+    low_rank = vec.bdot(Q, CQ).sum()
+    GQ = vec.gram(G, Q)                         # (s2, r)
+    Gp = vec.combine(-GQ, Q, G, 1.0)            # G - (G Q^T) Q
+    BG, xG = B(Gp)
+    CG = S_rows(BG)
+    resid = vec.bdot(Gp, CG).sum() / s2
+    value = float(low_rank + resid)
+    # ---- adjoint
+    CtQ, yQ = B(S_rows(Q))                      # C^T q = B S q ;  y = M^-1 W^T S q
+    CtG, yG = B(S_rows(Gp))
+    E = vec.lin([(1.0, CQ), (1.0, CtQ)])
+    H = vec.lin([(1.0, CG), (1.0, CtG)])
+    Ep = vec.combine(-vec.gram(E, Q), Q, E, 1.0)
+    HQ = vec.gram(H, Q)
+    Hp = vec.combine(-HQ, Q, H, 1.0)
+    coef = torch.cat([HQ.T, GQ.T], dim=1) * (-1.0 / s2)            # (r, 2 s2)
+    YbarR = vec.combine(coef, torch.cat([Gp, Hp], dim=0), Ep, 1.0)
+    Ybar = vec.combine(Cm.T.contiguous(), YbarR)                    # (s1, D)
+    BSY, yY = B(S_rows(Ybar))
+    # a b^T in Cbar  ->  -alpha^-1 [ (B S a) (M^-1 W^T b)^T + (B b) (M^-1 W^T S a)^T ]
+    m = -a_inv
+    terms = [(BSY, m * xS), (CtQ, m * xQ), (CtG, (m / s2) * xG),         # (a, b) = (ybar, s), (q, q), (g/s2, g)
+             (BS, m * yY), (BQ, m * yQ), (BG, (m / s2) * yG)]
+    return value, terms, dict(rank=r)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# SLQ on the bidiagonalisation of A v = [sqrt(alpha) v ; s_b W^T v]: value and cotangent of W
+# ----------------------------------------------------------------------------------------------------------------
+def _slq_small(alphas, betas, len2):
+    """mean_p ||p||^2 e1^T log(B^T B) e1 for upper-bidiagonal B (P, k, k) — differentiable float64 torch."""
+    Bm = torch.diag_embed(alphas)
+    if betas.shape[-1] > 0:
+        Bm = Bm + torch.diag_embed(betas, 1)
+    T = Bm.transpose(-1, -2) @ Bm
+    ev, U = torch.linalg.eigh(T)
+    return (len2 * (U[:, 0, :] ** 2 * torch.log(ev)).sum(-1)).mean()
+
+
+def _slq_value_and_terms(WT_rows, W_rows, D, d, alpha, s_b, probes, k, vec):
+    sa = math.sqrt(alpha)
+    dt = probes.dtype
+
+    def A(V):                                   # (P, D) -> (P, D + d)
+        return torch.cat([sa * V, s_b * WT_rows(V).to(dt)], dim=1).contiguous()
+
+    def AT(Uu):                                 # (P, D + d) -> (P, D)
+        return vec.lin([(sa, Uu[:, :D].contiguous()), (s_b, W_rows(Uu[:, D:].contiguous()))])
+
+    P = probes.shape[0]
+    len2 = vec.bdot(probes, probes)
+    al, be, Vb, Ub = vec.bidiag(A, AT, probes, k, D + d)
+    al64 = al.double().detach().clone().requires_grad_(True)
+    be64 = be.double().detach().clone().requires_grad_(True)
+    val = _slq_small(al64, be64, len2.to(al64.device))
+    gal, gbe = torch.autograd.grad(val, (al64, be64), allow_unused=True)
+    gbe = torch.zeros_like(be64) if gbe is None else gbe
+    al64, be64 = al64.detach(), be64.detach()
+    # ---- reverse mode over  alpha_j u_j = A v_j - beta_{j-1} u_{j-1} ;  beta_j v_{j+1} = A^T u_j - alpha_j v_j
+    dev = probes.device
+    zero_u = lambda: torch.zeros(P, D + d, dtype=dt, device=dev)
+    ubar = [None] * k                           # cotangents of u_j (filled lazily)
+    vbar_next = None                            # cotangent of v_{j+1}
+    bbar_extra = torch.zeros(P, dtype=torch.float64, device=dev)   # contribution to betabar_j from uhat_{j+1}
+    terms: List[Tuple[torch.Tensor, torch.Tensor]] = []
+    for j in range(k - 1, -1, -1):
+        vj, uj = Vb[:, j, :D].contiguous(), Ub[:, j, :D + d].contiguous()
+        vbar_j = None
+        abar = gal[:, j].clone()
+        if j + 1 < k:
+            vn = Vb[:, j + 1, :D].contiguous()
+            bj = be64[:, j]
+            bbar = gbe[:, j] + bbar_extra
+            if vbar_next is None:
+                what = vec.lin([(bbar, vn)])
+            else:
+                proj = vec.bdot(vn, vbar_next)
+                what = vec.lin([(1.0 / bj, vbar_next), (bbar - proj / bj, vn)])
+            # w_j = A^T u_j - alpha_j v_j
+            Aw = A(what)
+            ubar[j] = Aw if ubar[j] is None else vec.lin([(1.0, ubar[j]), (1.0, Aw)])
+            terms.append((what, s_b * uj[:, D:].double()))
+            abar = abar - vec.bdot(what, vj)
+            vbar_j = vec.lin([(-al64[:, j], what)])
+        ub = ubar[j] if ubar[j] is not None else zero_u()
+        # u_j = uhat_j / alpha_j
+        uhat = vec.lin([(1.0 / al64[:, j], ub), (abar - vec.bdot(uj, ub) / al64[:, j], uj)])
+        # uhat_j = A v_j - beta_{j-1} u_{j-1}
+        back = AT(uhat)
+        vbar_j = back if vbar_j is None else vec.lin([(1.0, vbar_j), (1.0, back)])
+        terms.append((vj, s_b * uhat[:, D:].double()))
+        if j > 0:
+            up = Ub[:, j - 1, :D + d].contiguous()
+            bbar_extra = -vec.bdot(uhat, up)
+            contrib = vec.lin([(-be64[:, j - 1], uhat)])
+            ubar[j - 1] = contrib if ubar[j - 1] is None else vec.lin([(1.0, ubar[j - 1]), (1.0, contrib)])
+        ubar[j] = None
+        vbar_next = vbar_j
+    return float(val.detach()), terms
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def stochastic_objective_and_cotangent(S_rows: Callable, WT_rows: Callable, W_rows: Callable, WTW: torch.Tensor, D: int,
+                                       alpha: float, beta: float, probes: torch.Tensor, st_samples: int, slq_samples: int,
+                                       slq_num_matvecs: int, logdet_beta: bool, vec):
+    """Value of ``alternative_objective_scalable`` (``src/train_inducing.py:87-173``) on the given probes and the
+    rank-one cotangent of W: ``(value, logdet_term, trace_term, terms)`` with ``dF = sum over (U, X) in terms, rows t:
+    U[t]^T dW X[t]``.
+
+    ``S_rows`` (P, D) -> (P, D) applies the data precision; ``WT_rows`` (P, D) -> (P, d) and ``W_rows`` (P, d) -> (P, D)
+    the factor of the inducing points (unscaled, ``full_set_size=None`` as at ``:112-114``); ``WTW`` its (d, d) Gram."""
+    d = WTW.shape[0]
+    I = torch.eye(d, dtype=torch.float64, device=WTW.device)
+    Minv = torch.linalg.inv(I / beta + WTW.double() / alpha)
+    Minv = 0.5 * (Minv + Minv.T)
+    s1, s2 = st_samples - 16, 16                                    # :143
+    trace_term, terms, _ = _hutchpp_value_and_terms(S_rows, WT_rows, W_rows, Minv, alpha, probes[:st_samples], s1, s2, vec)
+    s_b = math.sqrt(beta) if logdet_beta else 1.0
+    logdet_term, t2 = _slq_value_and_terms(WT_rows, W_rows, D, d, alpha, s_b, probes[:slq_samples].contiguous(),
+                                           slq_num_matvecs, vec)
+    return logdet_term + trace_term, logdet_term, trace_term, terms + t2

@@ -18,6 +18,16 @@ from .stochtrace import hutchpp_v2
 
 def alternative_objective_scalable(Z, X, state, alpha, model_type, probes, full_set_size, slq_samples=2,
                                    slq_num_matvecs=None, logdet_beta=True):
+    ld, tr = objective_stochastic_t(Z, X, state, alpha, model_type, probes, full_set_size, slq_samples, slq_num_matvecs,
+                                    logdet_beta)
+    return float(ld + tr), float(ld), float(tr)
+
+
+def objective_stochastic_t(Z, X, state, alpha, model_type, probes, full_set_size, slq_samples=2, slq_num_matvecs=None,
+                           logdet_beta=True):
+    """``alternative_objective_scalable`` (``:87-173``) as differentiable torch scalars ``(logdet_term, trace_term)``:
+    ``torch.autograd.grad`` of their sum w.r.t. Z is what ``jax.value_and_grad`` (``:196``) returns for the same
+    probes — reverse mode through Hutch++ (QR included) and through the re-orthogonalised bidiagonalisation."""
     N = full_set_size
     M = Z.shape[0]
     beta = N / M
@@ -44,7 +54,15 @@ def alternative_objective_scalable(Z, X, state, alpha, model_type, probes, full_
     AT = lambda u: sa * u[:D] + Wz((sb * u[D:]).reshape(inner))
     quad = integrand_funm_product_logdet(bidiag(k))
     logdet_term = torch.stack([quad(A, AT, p) for p in probes[:slq_samples]]).mean()
-    return float(logdet_term + trace_term), float(logdet_term), float(trace_term)
+    return logdet_term, trace_term
+
+
+def variational_grad_stochastic(Z, X, state, alpha, model_type, probes, full_set_size, **kw):
+    """(value, d value / dZ) of the stochastic objective on fixed probes (``src/train_inducing.py:196``)."""
+    Zr = Z.clone().requires_grad_(True)
+    ld, tr = objective_stochastic_t(Zr, X, state, alpha, model_type, probes, full_set_size, **kw)
+    g, = torch.autograd.grad(ld + tr, Zr)
+    return float((ld + tr).detach()), g
 
 
 # ---- gradients w.r.t. Z: ``jax.value_and_grad`` of the objectives (``src/train_inducing.py:195-196``) -------------

