@@ -114,20 +114,42 @@ def _act2(name: str, a: torch.Tensor, dphi: Optional[torch.Tensor], y: Optional[
     raise ValueError(name)
 
 
-def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str) -> torch.Tensor:
-    """grad_Z of  sum_{i,k} < J(z_i) Mdir[i, k] , c_out L(z_i) e_k >  for the binding behind ``ex``.
+def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str, out_weights: Optional[torch.Tensor] = None,
+                          shared: bool = False) -> torch.Tensor:
+    """grad_Z of the parameter-JVP pairing of the binding behind ``ex``, T directions per example:
 
-    ``Mdir`` is (n, K, D) on the executor's device: direction k of example i.  Returns (n, *input_shape_raw)."""
+      per-example directions (default):  sum_{i,t} < J(z_i) Mdir[i, t] , c_out L(z_i) x_it >,   Mdir (n, T, D)
+      ``shared=True``:                   sum_{i,t} < J(z_i) Mdir[t]    , c_out L(z_i) x_it >,   Mdir (T, D)
+
+    with x_it = ``out_weights[i, t]`` (n, T, K); ``None`` means x_it = e_t (T = K, the exact objective's pairing).
+    Shared directions are what the rank-one cotangent of the stochastic objective consists of (``stochastic_grad.py``):
+    the tangent pass is then the engine's ordinary probe-batched one (one launch per segment for all examples and
+    directions).  Returns (n, *input_shape_raw)."""
     cn = ex.cn
     net, n, D, K = cn.net, cn.n, cn.D, cn.K
     dev, dt = ex.device, ex.dtype
     tens = net.tensors
     meta = cn.meta
     layout = meta["layout"]
-    if tuple(Mdir.shape) != (n, K, D):
-        raise ValueError(f"directions must be (n, K, D) = {(n, K, D)}, got {tuple(Mdir.shape)}")
-    if K > ex.max_probes:
-        raise NotImplementedError(f"second-order pass: K = {K} probes exceed the engine's chunk of {ex.max_probes}")
+    if shared:
+        if Mdir.dim() != 2 or Mdir.shape[1] != D:
+            raise ValueError(f"shared directions must be (T, D) with D = {D}, got {tuple(Mdir.shape)}")
+        T = int(Mdir.shape[0])
+    else:
+        if Mdir.dim() != 3 or Mdir.shape[0] != n or Mdir.shape[2] != D:
+            raise ValueError(f"directions must be (n, T, D) = ({n}, T, {D}), got {tuple(Mdir.shape)}")
+        T = int(Mdir.shape[1])
+    if out_weights is None:
+        if T != K:
+            raise ValueError(f"without out_weights the pairing takes T = K = {K} directions (x_it = e_t), got {T}")
+        Xw = torch.eye(K, device=dev, dtype=torch.float64)[None].expand(n, K, K)
+    else:
+        if tuple(out_weights.shape) != (n, T, K):
+            raise ValueError(f"out_weights must be (n, T, K) = {(n, T, K)}, got {tuple(out_weights.shape)}")
+        Xw = out_weights.to(device=dev, dtype=torch.float64)
+    if T > ex.max_probes:
+        raise NotImplementedError(f"second-order pass: {T} directions exceed the engine's chunk of {ex.max_probes} "
+                                  "(split the directions: the pairing is a sum over them)")
     Mdir = Mdir.to(device=dev, dtype=dt).contiguous()
     classifier = model_type == "classifier"
 
@@ -142,12 +164,13 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         return ex.prim[off:off + count]
 
     def pdir(path):
-        """(K, n, numel) view of the direction's slice for one parameter leaf."""
+        """(T, n, numel) view — (T, 1, numel) for shared directions — of the direction's slice for one parameter leaf."""
         off, shape = layout[path]
         cnt = math.prod(shape) if shape else 1
+        if shared:
+            return Mdir[:, None, off:off + cnt]
         return Mdir[:, :, off:off + cnt].permute(1, 0, 2)
 
-    producer = {u.dst: u for u in net.units}
     has_tan: Dict[int, bool] = {0: False}
     for u in net.units:
         has_tan[u.dst] = True if u.kind == "conv" else has_tan[u.src]
@@ -171,10 +194,10 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         if root(t) != t:
             continue
         if has_tan.get(t, False):
-            alloc(f"T{t}", K * n * size(t))
-            alloc(f"DA{t}", K * n * size(t))
+            alloc(f"T{t}", T * n * size(t))
+            alloc(f"DA{t}", T * n * size(t))
         alloc(f"A{t}", n * size(t))
-    for nm, cnt in (("ACC", K * n * maxsz), ("SDY", K * n * maxsz), ("SZB", n * maxsz), ("TMP", K * n * maxsz)):
+    for nm, cnt in (("ACC", T * n * maxsz), ("SDY", T * n * maxsz), ("SZB", n * maxsz), ("TMP", T * n * maxsz)):
         alloc(nm, cnt)
     arena = torch.zeros(top, device=dev, dtype=dt)
 
@@ -198,10 +221,8 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
     def bn_factors(u):
         if u.bn_scale is None:
             return None
-        so = meta["s_off"][u.dst]
-        s = ex.consts[so:so + u.cout]
-        gamma = ex.theta[poff(u.bn_scale):poff(u.bn_scale) + u.cout]
-        return s, gamma
+        so, ro = meta["s_off"][u.dst], meta["rstd_off"][u.dst]
+        return ex.consts[so:so + u.cout], ex.consts[ro:ro + u.cout]          # s = gamma rstd, rstd
 
     def unit_primals(u):
         """(a, dphi or None, act'' or None) of unit u's output, each (n, size) or None"""
@@ -227,64 +248,73 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         src, dst = root(u.src), u.dst
         if u.kind == "meanpool":
             h, w, c = tens[u.src]
-            Ts = buf(f"T{src}", K, n, h * w, c)
-            buf(f"T{dst}", K, n, c).copy_(Ts.mean(2))
+            Ts = buf(f"T{src}", T, n, h * w, c)
+            buf(f"T{dst}", T, n, c).copy_(Ts.mean(2))
             continue
         if u.kind in ("maxpool", "avgpool"):
             am = meta["amax_off"][dst]
             amax = NONE if am is None else _ref(nv.SP_PRIM, am)
             ex.run(_pool(nv.OP_MAXPOOL_FWD, n, u, tens, Y(f"T{src}", 0, n * size(u.src)), Y(f"T{dst}", 0, n * size(dst)), amax),
-                   K, Mdir, arena)
+                   T, Mdir, arena)
             continue
         if u.kind != "conv":
             raise NotImplementedError(f"second-order pass: unit kind '{u.kind}' is not supported")
         oh, ow, co = tens[dst]
         sz, ssz = size(dst), size(u.src)
-        acc = buf("ACC", K, n, sz)
-        shared = has_tan[u.src]
-        if shared:   # conv(da, W) over all examples
+        acc = buf("ACC", T, n, sz)
+        has_in = has_tan[u.src]
+        if has_in:   # conv(da, W) over all examples
             ex.run(_igemm(n, oh, ow, co, dict(geom(u), a=Y(f"T{src}", 0, n * ssz), b=_ref(nv.SP_THETA, poff(u.kernel))),
-                          Y("ACC", 0, n * sz)), K, Mdir, arena)
-        # + conv(a_i, dW_ik): the weight tangent is the example's own.  One launch per direction k with the EXAMPLES on
-        # the probe axis (n_img = 1, "probe" i reads a_i, dW_ik and writes slot (k, i)): every operand offset is linear in i
-        for k in range(K):
-            for i0 in range(0, n, ex.max_probes):
-                seg = dict(geom(u), a=_ref(nv.SP_PRIM, cn.a_off[u.src] + i0 * ssz, ssz),
-                           b=_ref(nv.SP_VIN, (i0 * K + k) * D + poff(u.kernel), K * D))
-                o = Y("ACC", (k * n + i0) * sz, sz)
-                ex.run(_igemm(1, oh, ow, co, seg, o, res=o if shared else None), min(ex.max_probes, n - i0), Mdir, arena)
+                          Y("ACC", 0, n * sz)), T, Mdir, arena)
+        if shared:
+            # + conv(a, dW_t): the direction is the same for every example — the engine's own probe-batched segment
+            seg = dict(geom(u), a=_ref(nv.SP_PRIM, cn.a_off[u.src], 0), b=_ref(nv.SP_VIN, poff(u.kernel), D))
+            o = Y("ACC", 0, n * sz)
+            ex.run(_igemm(n, oh, ow, co, seg, o, res=o if has_in else None), T, Mdir, arena)
+        else:
+            # + conv(a_i, dW_it): the weight tangent is the example's own.  One launch per direction t with the EXAMPLES
+            # on the probe axis (n_img = 1, "probe" i reads a_i, dW_it and writes slot (t, i)): every operand offset is
+            # linear in i
+            for k in range(T):
+                for i0 in range(0, n, ex.max_probes):
+                    seg = dict(geom(u), a=_ref(nv.SP_PRIM, cn.a_off[u.src] + i0 * ssz, ssz),
+                               b=_ref(nv.SP_VIN, (i0 * T + k) * D + poff(u.kernel), T * D))
+                    o = Y("ACC", (k * n + i0) * sz, sz)
+                    ex.run(_igemm(1, oh, ow, co, seg, o, res=o if has_in else None), min(ex.max_probes, n - i0), Mdir, arena)
         a, dphi, _ = unit_primals(u)
-        dy = acc.view(K, n, oh * ow, co)
+        dy = acc.view(T, n, oh * ow, co)
         bn = bn_factors(u)
         if bn is not None:
-            s, gamma = bn
+            s, _ = bn
             xhat = prim(meta["xhat_off"][dst], n * sz).view(1, n, oh * ow, co)
-            dy = dy * s + pdir(u.bn_scale).view(K, n, 1, co) * xhat + pdir(u.bn_bias).view(K, n, 1, co)
+            dy = dy * s + pdir(u.bn_scale).unsqueeze(2) * xhat + pdir(u.bn_bias).unsqueeze(2)
         elif u.bias is not None:
-            dy = dy + pdir(u.bias).view(K, n, 1, co)
-        dy = dy.reshape(K, n, sz)
+            dy = dy + pdir(u.bias).unsqueeze(2)
+        dy = dy.reshape(T, n, sz)
         if u.res is not None and has_tan[u.res]:
-            dy = dy + buf(f"T{root(u.res)}", K, n, sz)
+            dy = dy + buf(f"T{root(u.res)}", T, n, sz)
         if u.act in ("tanh", "gelu"):
             dys[dst] = dy.clone()
-        buf(f"T{dst}", K, n, sz).copy_(dy * dphi if dphi is not None else dy)
+        buf(f"T{dst}", T, n, sz).copy_(dy * dphi if dphi is not None else dy)
 
     # ---------------------------------------------------------------- head: adjoints of the logits' tangent / value
+    # phi_i = sum_t < U_it , c L(p(f_i)) x_it >:  DA = d phi / d U = c L x (per direction),  A = d phi / d f through p —
+    # a K-sized closed form per example, differentiated by autograd on the (n, K) logits (T n K elements)
     out_t = root(net.out)
-    U = buf(f"T{out_t}", K, n, K).permute(1, 0, 2).double()           # U[i, k, a] = (J(z_i) m_ik)_a
+    U = buf(f"T{out_t}", T, n, K).permute(1, 0, 2).double()           # U[i, t, a] = (J(z_i) m_it)_a
     if classifier:
-        p = prim(cn.prob_off, n * K).view(n, K).double()
-        s = torch.sqrt(p)
-        eye = torch.eye(K, device=dev, dtype=torch.float64)
-        ubar = c_out * s[:, :, None] * (eye[None] - p[:, None, :])     # [i, k, a] = c s_ik (delta_ak - p_ia) = c (L e_k)_a
-        d = torch.diagonal(U, dim1=1, dim2=2)                          # U[i, k, k]
-        w = (U * p[:, None, :]).sum(-1)                                # sum_a p_a U[i, k, a]
-        g = s * (d - w)                                                # s_k (d_k - w_k)
-        fbar = c_out * (0.5 * g - 0.5 * p * g.sum(-1, keepdim=True) - p * ((s[:, :, None] * (U - w[:, :, None])).sum(1)))
+        f = prim(cn.a_off[net.out], n * K).view(n, K).double().clone().requires_grad_(True)
+        with torch.enable_grad():
+            p = torch.softmax(f, dim=-1)
+            sq = torch.sqrt(p)
+            Lx = sq[:, None, :] * Xw - p[:, None, :] * (sq[:, None, :] * Xw).sum(-1, keepdim=True)   # (L x)_a = s_a x_a - p_a <s, x>
+            phi = c_out * (U.detach() * Lx).sum()
+            fbar, = torch.autograd.grad(phi, f)
+        ubar = (c_out * Lx).detach()
     else:
-        ubar = torch.full((n, K, K), float(c_out), device=dev, dtype=torch.float64) * torch.eye(K, device=dev, dtype=torch.float64)
+        ubar = float(c_out) * Xw
         fbar = torch.zeros(n, K, device=dev, dtype=torch.float64)
-    buf(f"DA{out_t}", K, n, K).copy_(ubar.permute(1, 0, 2).to(dt))
+    buf(f"DA{out_t}", T, n, K).copy_(ubar.permute(1, 0, 2).to(dt))
     buf(f"A{out_t}", n, K).copy_(fbar.to(dt))
 
     # ---------------------------------------------------------------- reverse
@@ -295,7 +325,7 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         if u.kind == "meanpool":
             h, w, c = tens[u.src]
             if has_tan[u.src]:
-                buf(f"DA{src}", K, n, h * w, c).add_(buf(f"DA{dst}", K, n, 1, c) / (h * w))
+                buf(f"DA{src}", T, n, h * w, c).add_(buf(f"DA{dst}", T, n, 1, c) / (h * w))
             buf(f"A{src}", n, h * w, c).add_(buf(f"A{dst}", n, 1, c) / (h * w))
             continue
         if u.kind in ("maxpool", "avgpool"):
@@ -303,8 +333,8 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
             amax = NONE if am is None else _ref(nv.SP_PRIM, am)
             sz, ssz = size(dst), size(u.src)
             if has_tan[u.src]:
-                ex.run(_pool(nv.OP_MAXPOOL_BWD, n, u, tens, Y(f"DA{dst}", 0, n * sz), Y("TMP", 0, n * ssz), amax), K, Mdir, arena)
-                buf(f"DA{src}", K, n, ssz).add_(buf("TMP", K, n, ssz))
+                ex.run(_pool(nv.OP_MAXPOOL_BWD, n, u, tens, Y(f"DA{dst}", 0, n * sz), Y("TMP", 0, n * ssz), amax), T, Mdir, arena)
+                buf(f"DA{src}", T, n, ssz).add_(buf("TMP", T, n, ssz))
             ex.run(_pool(nv.OP_MAXPOOL_BWD, n, u, tens, Y(f"A{dst}", 0, 0), Y("TMP", 0, 0), amax), 1, Mdir, arena)
             buf(f"A{src}", n, ssz).add_(buf("TMP", n, ssz))
             continue
@@ -312,7 +342,7 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         sz, ssz = size(dst), size(u.src)
         sh, sw, sc = tens[u.src]
         a, dphi, ddphi = unit_primals(u)
-        DA, AB = buf(f"DA{dst}", K, n, sz), buf(f"A{dst}", n, sz)
+        DA, AB = buf(f"DA{dst}", T, n, sz), buf(f"A{dst}", n, sz)
         DYb = DA * dphi if dphi is not None else DA
         Yb = AB * dphi if dphi is not None else AB.clone()
         if ddphi is not None:
@@ -320,32 +350,37 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
         if u.res is not None:
             r = root(u.res)
             if has_tan[u.res]:
-                buf(f"DA{r}", K, n, sz).add_(DYb)
+                buf(f"DA{r}", T, n, sz).add_(DYb)
             buf(f"A{r}", n, sz).add_(Yb)
         bn = bn_factors(u)
-        sdy, szb = buf("SDY", K, n, oh * ow, co), buf("SZB", n, oh * ow, co)
-        DYv, Ybv = DYb.reshape(K, n, oh * ow, co), Yb.reshape(n, oh * ow, co)
+        sdy, szb = buf("SDY", T, n, oh * ow, co), buf("SZB", n, oh * ow, co)
+        DYv, Ybv = DYb.reshape(T, n, oh * ow, co), Yb.reshape(n, oh * ow, co)
         if bn is not None:
-            s, gamma = bn
-            ratio = pdir(u.bn_scale).view(K, n, 1, co) / gamma          # dgamma_ik / gamma
+            s, rstd = bn
+            # x-hat depends on z: its adjoint is dgamma_t rstd DY_t (written with rstd, not (dgamma / gamma) s, so a
+            # zero-initialised BN scale gives 0, not inf * 0)
             sdy.copy_(DYv * s)
-            szb.copy_((Ybv + (ratio * DYv).sum(0)) * s)
+            szb.copy_(Ybv * s + (pdir(u.bn_scale).unsqueeze(2) * rstd * DYv).sum(0))
         else:
             sdy.copy_(DYv)
             szb.copy_(Ybv)
-        tmp = buf("TMP", K, n, ssz)
+        tmp = buf("TMP", T, n, ssz)
         wref = _ref(nv.SP_THETA, poff(u.kernel))
         if has_tan[u.src]:   # DA_src += convT(s DY, W)
-            ex.run(_igemm(n, sh, sw, sc, dict(geom_t(u), a=Y("SDY", 0, n * sz), b=wref), Y("TMP", 0, n * ssz)), K, Mdir, arena)
-            buf(f"DA{src}", K, n, ssz).add_(tmp)
+            ex.run(_igemm(n, sh, sw, sc, dict(geom_t(u), a=Y("SDY", 0, n * sz), b=wref), Y("TMP", 0, n * ssz)), T, Mdir, arena)
+            buf(f"DA{src}", T, n, ssz).add_(tmp)
         # A_src += convT(s Z', W)   (one "probe")
         ex.run(_igemm(n, sh, sw, sc, dict(geom_t(u), a=Y("SZB", 0, 0), b=wref), Y("TMP", 0, 0)), 1, Mdir, arena)
         buf(f"A{src}", n, ssz).add_(buf("TMP", n, ssz))
-        # A_src_i += sum_k convT(s DY_ik, dW_ik)
-        for k in range(K):   # examples on the probe axis, as in the forward pass
-            for i0 in range(0, n, ex.max_probes):
-                seg = dict(geom_t(u), a=Y("SDY", (k * n + i0) * sz, sz), b=_ref(nv.SP_VIN, (i0 * K + k) * D + poff(u.kernel), K * D))
-                ex.run(_igemm(1, sh, sw, sc, seg, Y("TMP", (k * n + i0) * ssz, ssz)), min(ex.max_probes, n - i0), Mdir, arena)
+        # A_src_i += sum_t convT(s DY_it, dW_it)
+        if shared:
+            seg = dict(geom_t(u), a=Y("SDY", 0, n * sz), b=_ref(nv.SP_VIN, poff(u.kernel), D))
+            ex.run(_igemm(n, sh, sw, sc, seg, Y("TMP", 0, n * ssz)), T, Mdir, arena)
+        else:
+            for k in range(T):   # examples on the probe axis, as in the forward pass
+                for i0 in range(0, n, ex.max_probes):
+                    seg = dict(geom_t(u), a=Y("SDY", (k * n + i0) * sz, sz), b=_ref(nv.SP_VIN, (i0 * T + k) * D + poff(u.kernel), T * D))
+                    ex.run(_igemm(1, sh, sw, sc, seg, Y("TMP", (k * n + i0) * ssz, ssz)), min(ex.max_probes, n - i0), Mdir, arena)
         buf(f"A{src}", n, ssz).add_(tmp.sum(0))
 
     h0, w0, c0 = tens[0]
@@ -354,3 +389,25 @@ def input_grad_of_pairing(ex, Mdir: torch.Tensor, c_out: float, model_type: str)
     if t > 1:
         g = g.reshape(n, h0, w0, t, c0 // t).sum(3)
     return g.reshape((n,) + tuple(net.input_shape_raw)).clone()
+
+
+def input_grad_of_rank_one_terms(ex, terms, c_out: float, model_type: str, max_directions: Optional[int] = None) -> torch.Tensor:
+    """grad_Z of  sum over (U, X) in ``terms``, rows t:  U[t]^T W(Z) X[t]  =  sum_t sum_i < J(z_i) U[t] , c L(z_i) X[t, i] >
+    — the cotangent of the factor W as ``stochastic_grad.stochastic_objective_and_cotangent`` returns it (U (T_b, D),
+    X (T_b, n K)).  The pairing is a sum over the directions, so they are consumed in chunks of at most
+    ``max_directions`` (default: what the engine's probe chunk and ~1/4 of the free device memory allow)."""
+    cn = ex.cn
+    n, K = cn.n, cn.K
+    per_dir = 4 * n * (2 * sum(h * w * c for (h, w, c) in cn.net.tensors) + 3 * max(h * w * c for (h, w, c) in cn.net.tensors)) + 4 * cn.D
+    if max_directions is None:
+        free = torch.cuda.mem_get_info(ex.device)[0] if ex.device.type == "cuda" else (8 << 30)
+        max_directions = max(1, min(ex.max_probes, int(free // 4 // per_dir)))
+    max_directions = min(int(max_directions), ex.max_probes)
+    g = None
+    for U, X in terms:
+        for t0 in range(0, U.shape[0], max_directions):
+            Ub = U[t0:t0 + max_directions]
+            Xb = X[t0:t0 + max_directions].reshape(Ub.shape[0], n, K).permute(1, 0, 2)
+            gi = input_grad_of_pairing(ex, Ub, c_out, model_type, out_weights=Xb, shared=True)
+            g = gi if g is None else g + gi
+    return g

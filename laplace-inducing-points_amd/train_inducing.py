@@ -3,8 +3,10 @@
 ``alternative_objective_dense`` (``:176-193``), ``alternative_objective_scalable_exact`` (``:26-84``) and
 ``alternative_objective_scalable`` (``:87-173``): KL[q(theta|Z) || q(theta|data)] up to constants =
 log-det term + trace term, and their gradients w.r.t. Z (``value_and_grad`` at ``:195-196``, ``optimize_step``
-``:199-232``): exact, with every D-sized quantity on the HIP engine, including the last, second-order step (the input
-derivative of a parameter-JVP: reverse mode over the tangent tape, ``second_order.py``).
+``:199-232``): of the exact objective through materialised factors, or — the reference's own quantity — of the
+stochastic Hutch++ / SLQ estimate, matrix-free (``stochastic_grad.py``); every D-sized quantity on the HIP engine,
+including the last, second-order step (the input derivative of a parameter-JVP: reverse mode over the tangent tape,
+``second_order.py``).
 
 SURVEY §4.1-9: the reference's stochastic log-det omits beta (it bidiagonalises v -> [sqrt(alpha) v ; Wz^T v],
 ``:164-169``, i.e. log|alpha I + Wz Wz^T|) while its exact twin uses beta (``:68``).  ``logdet_beta=True`` (default)
@@ -154,9 +156,86 @@ def _input_grad_of_pairing(state, Z, Mrow, model_type):
     return input_grad_of_pairing(EngineExecutor(eng), Mrow.reshape(eng.n, eng.K, eng.D), _c_out(state, model_type), model_type)
 
 
+EXACT_FACTOR_BYTES = 24 << 30      # "auto": the exact route materialises the factor of x_chunk data images (x_chunk K D floats)
+
+
 def variational_grad_scalable(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None,
-                              x_chunk: Optional[int] = None, _with_constants: bool = False, **_):
+                              x_chunk: Optional[int] = None, method: str = "auto", **kw):
     """``jax.value_and_grad(alternative_objective_scalable)`` (``src/train_inducing.py:196``) -> ``(loss, dLoss/dZ)``.
+
+    ``method="stochastic"`` is the reference's own quantity: value and gradient of the Hutch++ / SLQ ESTIMATE on the
+    probes drawn from ``key`` (:func:`variational_grad_stochastic`; matrix-free — the data batch enters through
+    products with the data precision only, so it runs where a factor of the batch does not fit: BASELINE configs[4]).
+    ``method="exact"``: value and gradient of the exact objective those estimators target, through materialised
+    factors (:func:`variational_grad_exact`; no estimator variance, needs x_chunk K D floats per data chunk).
+    ``method="auto"`` (default) takes "exact" while the factors of Z and of one data chunk fit ``EXACT_FACTOR_BYTES``
+    and "stochastic" beyond that."""
+    if method == "auto":
+        K, D = _out_dim(state, Z, model_type), _D(state)
+        rows = max(Z.shape[0], min(x_chunk or X.shape[0], X.shape[0])) * K
+        method = "exact" if rows * D * 4 <= EXACT_FACTOR_BYTES else "stochastic"
+    if method == "exact":
+        return variational_grad_exact(Z, X, state, alpha, key=key, model_type=model_type, full_set_size=full_set_size,
+                                      x_chunk=x_chunk, **{k: v for k, v in kw.items() if k == "_with_constants"})
+    if method != "stochastic":
+        raise ValueError("method must be 'auto', 'exact' or 'stochastic'")
+    skw = {k: v for k, v in kw.items() if k in ("st_samples", "slq_samples", "slq_num_matvecs", "logdet_beta", "probes",
+                                                 "example_chunk", "max_directions")}
+    return variational_grad_stochastic(Z, X, state, alpha, key=key, model_type=model_type, full_set_size=full_set_size, **skw)
+
+
+def _out_dim(state, Z, model_type):
+    from .ggn import get_engine
+    return get_engine(state, Z, model_type).K
+
+
+def variational_grad_stochastic(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None, st_samples=256,
+                                slq_samples=2, slq_num_matvecs: Optional[int] = None, logdet_beta: bool = True,
+                                probes: Optional[torch.Tensor] = None, example_chunk: Optional[int] = None,
+                                max_directions: Optional[int] = None, return_terms: bool = False):
+    """Value and EXACT gradient of the stochastic objective ``alternative_objective_scalable`` (``src/train_inducing.py:
+    87-173``) on fixed probes — what ``jax.value_and_grad`` returns at ``:196``: reverse mode through Hutch++ (the QR
+    included) and through the bidiagonalisation SLQ, matrix-free (``stochastic_grad.py`` for the adjoint algebra).
+
+    Cost: 2 (2 s1 + s2) products with the data precision (the value alone needs 2 s1 + s2), (4 s1 + 2 s2 + 4 k slq)
+    sweep pairs on the inducing points' engine, one d x d Gram, and one second-order pass over the
+    2 (2 s1 + s2) + 2 k slq rank-one directions.  ``example_chunk`` bounds the data images per engine binding
+    (``ExampleChunkedGGN``), ``max_directions`` the directions per second-order pass."""
+    from . import stochastic_grad as SG
+    from .ggn import ExampleChunkedGGN
+    from .second_order import EngineExecutor, input_grad_of_rank_one_terms
+    N = full_set_size or Z.shape[0]
+    M = Z.shape[0]
+    beta = N / M
+    if example_chunk is not None and X.shape[0] > example_chunk:
+        opS = ExampleChunkedGGN(state, X, model_type, full_set_size=N, example_chunk=example_chunk)
+        S_rows = lambda V: opS(V, float(alpha))
+    else:
+        S_rows = compute_curvature_approx(state, X, alpha=alpha, model_type=model_type, full_set_size=N).rows
+    Wz, WzT = compute_W_vps(state, Z, model_type=model_type, full_set_size=None)
+    eng = Wz.engine
+    D, dev = eng.D, eng.device
+    inner = WzT.out_shape
+    d_z = math.prod(inner)
+    WzTWz = build_WTW(Wz, WzT, inner, d_z, dtype=torch.float64, block=1)
+    if probes is None:
+        probes = krylov.fill_rademacher(st_samples, D, int(key or 0), dev)        # same probes for both terms, :139-142
+    st_samples = probes.shape[0]
+    k = slq_num_matvecs if slq_num_matvecs is not None else max(1, int(M * 0.8))   # :148
+    WT_rows = lambda V: WzT.rows(V.contiguous()).reshape(V.shape[0], d_z)
+    W_rows = lambda Xs: Wz.rows(Xs.to(torch.float32).reshape((Xs.shape[0],) + inner).contiguous())
+    value, ld, tr, terms = SG.stochastic_objective_and_cotangent(S_rows, WT_rows, W_rows, WzTWz, D, alpha, beta, probes,
+                                                                 st_samples, slq_samples, k, logdet_beta, SG.HipVec())
+    gZ = input_grad_of_rank_one_terms(EngineExecutor(eng), terms, _c_out(state, model_type), model_type, max_directions)
+    gZ = gZ.reshape(Z.shape).to(Z.dtype)
+    if return_terms:
+        return value, gZ, dict(logdet_term=ld, trace_term=tr, directions=sum(int(U.shape[0]) for U, _ in terms))
+    return value, gZ
+
+
+def variational_grad_exact(Z, X, state, alpha, key=None, model_type="classifier", full_set_size=None,
+                           x_chunk: Optional[int] = None, _with_constants: bool = False, **_):
+    """Value and gradient of the EXACT objective the reference's estimators target.
 
     The objective is F(Z) = tr(P S_z) + log det P_z  (P = alpha I + gamma G_X the data precision, S_z = P_z^-1), the
     quantity the reference's Hutch++ / SLQ estimators target (``:87-173``; exact twin ``:26-84``).  Returned are its
@@ -209,8 +288,8 @@ def variational_grad_dense(Z, X, state, alpha, key=None, model_type="classifier"
     ``S_z`` are the PRECISIONS returned by ``compute_curvature_approx_dense`` (``:181-183``), so the value is
     tr(P P_z^-1) + log det P_z — the same function of Z as the scalable objective plus the two constants that one
     drops.  Nothing D x D is formed here: same factor algebra, constants added back."""
-    return variational_grad_scalable(Z, X, state, alpha, key=key, model_type=model_type, full_set_size=full_set_size,
-                                     _with_constants=True, **kw)
+    return variational_grad_exact(Z, X, state, alpha, key=key, model_type=model_type, full_set_size=full_set_size,
+                                  _with_constants=True, **kw)
 
 
 def optimize_step(Z, X, map_model_state, alpha, opt_state, rng, zoptimizer, num_mc_samples=None, model_type="classifier",

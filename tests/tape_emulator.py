@@ -35,7 +35,7 @@ class TapeMachine:
         buf = self._buf(ref.space)
         off = ref.off * (self.chunk if ref.space == nv.SP_WORK else 1)
         ps = ref.pstride
-        return torch.as_strided(buf, (P, count), (ps, 1), off)
+        return torch.as_strided(buf, (P, count), (ps, 1), off + buf.storage_offset())     # as_strided offsets are storage-absolute
 
     # ------------------------------------------------------------------ ops
     def _gather(self, seg, P, n, OH, OW):

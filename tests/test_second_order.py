@@ -129,3 +129,88 @@ def test_second_order_pass_on_the_hip_engine(name):
     got = so.input_grad_of_pairing(so.EngineExecutor(eng), Mdir.cuda().float(), c, mt).double().cpu()
     ref = _reference(st, Z, Mdir, c, mt)
     assert (got - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+
+
+def _reference_shared(st, Z, Udir, Xw, c, model_type):
+    """grad_Z of  sum_{i,t} < J(z_i) u_t , c L(z_i) x_it >  (shared directions, general output weights), float64."""
+    net = st.net
+    flat, unravel = flatten_nn_params(st.params)
+
+    def f(theta, z):
+        return net.forward(unravel(theta), st.batch_stats, z).reshape(-1)
+
+    def phi_one(z, Xi):
+        JM = torch.stack([jvp(lambda th: f(th, z), (flat,), (u,))[1] for u in Udir])      # row t = J(z) u_t
+        if model_type == "classifier":
+            p = torch.softmax(f(flat, z), dim=-1)
+            sq = torch.sqrt(p)
+            L = torch.diag(sq) - torch.outer(p, sq)
+            return c * (JM * (Xi @ L.T)).sum()
+        return c * (JM * Xi).sum()
+
+    return torch.stack([grad(lambda z: phi_one(z, Xw[j]))(Z[j]) for j in range(Z.shape[0])])
+
+
+@pytest.mark.parametrize("name", ["xor_tanh_mlp", "sine_gelu_mlp", "resnet_bn_res_stride2", "stem_maxpool"])
+def test_shared_direction_pairing_on_the_tape_emulator(name):
+    """The cotangent of the stochastic objective is a sum of rank-one terms u_t x_t^T (``stochastic_grad.py``): T
+    directions shared by the examples, arbitrary output weights, consumed in chunks."""
+    net, Z, mt = _cases()[name]
+    st = create_state(net, 5, dtype=F64, logvar=-0.4)
+    n = Z.shape[0]
+    cn = compile_net(net, n, st.params)
+    T = 5
+    g = torch.Generator().manual_seed(9)
+    Udir = torch.randn(T, cn.D, dtype=F64, generator=g)
+    Xw = torch.randn(n, T, cn.K, dtype=F64, generator=g)
+    c = math.exp(0.2) if mt == "regressor" else 1.0
+    ex = _EmulatorExecutor(cn, st, Z, T)
+    got = so.input_grad_of_pairing(ex, Udir, c, mt, out_weights=Xw, shared=True)
+    ref = _reference_shared(st, Z, Udir, Xw, c, mt)
+    assert (got - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+    # the chunked driver over (U, X) blocks gives the same sum
+    ex2 = _EmulatorExecutor(cn, st, Z, 2)
+    X2 = Xw.permute(1, 0, 2).reshape(T, n * cn.K)
+    got2 = so.input_grad_of_rank_one_terms(ex2, [(Udir[:3], X2[:3]), (Udir[3:], X2[3:])], c, mt, max_directions=2)
+    assert (got2 - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item())
+
+
+def test_zero_bn_scale_gives_a_finite_gradient():
+    """A BatchNorm scale that is exactly zero (zero-initialised residual gamma): the x-hat adjoint is dgamma rstd DY,
+    not (dgamma / gamma) (gamma rstd) DY = inf * 0."""
+    net, Z, mt = _cases()["resnet_bn_res_stride2"]
+    st = create_state(net, 5, dtype=F64, logvar=-0.4)
+    bn_path = next(u.bn_scale for u in net.units if getattr(u, "bn_scale", None) is not None)
+    node = st.params                                  # the path starts at the top level ('params', ..., 'scale')
+    for key in bn_path[:-1]:
+        node = node[key]
+    node[bn_path[-1]].zero_()
+    n = Z.shape[0]
+    cn = compile_net(net, n, st.params)
+    Mdir = torch.randn(n, cn.K, cn.D, dtype=F64, generator=torch.Generator().manual_seed(9))
+    got = so.input_grad_of_pairing(_EmulatorExecutor(cn, st, Z, cn.K), Mdir, 1.0, mt)
+    ref = _reference(st, Z, Mdir, 1.0, mt)
+    assert bool(torch.isfinite(got).all())
+    assert (got - ref).abs().max().item() <= 1e-10 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["xor_tanh_mlp", "resnet_bn_res_stride2", "stem_maxpool", "resnet_fast_kernels"])
+def test_shared_direction_pairing_on_the_hip_engine(name):
+    from lip_amd.engine import LinearizedNet
+    if name == "resnet_fast_kernels":
+        net, Z, mt = ResNet1M(4, input_shape=(8, 8, 3), widths=(16, 32), blocks_per_stage=1), \
+            torch.rand(3, 8, 8, 3, dtype=F64, generator=torch.Generator().manual_seed(4)), "classifier"
+    else:
+        net, Z, mt = _cases()[name]
+    st = create_state(net, 5, dtype=F64, logvar=-0.4)
+    n = Z.shape[0]
+    eng = LinearizedNet(st.to(device="cuda", dtype=torch.float32), Z.cuda().float(), mt, workspace_bytes=1 << 28, max_chunk=16)
+    T = 7
+    g = torch.Generator().manual_seed(9)
+    Udir = torch.randn(T, eng.D, dtype=F64, generator=g)
+    Xw = torch.randn(n, T, eng.K, dtype=F64, generator=g)
+    got = so.input_grad_of_rank_one_terms(so.EngineExecutor(eng), [(Udir.cuda().float(), Xw.permute(1, 0, 2).reshape(T, -1).cuda())],
+                                          1.0, mt, max_directions=4).double().cpu()
+    ref = _reference_shared(st, Z, Udir, Xw, 1.0, mt)
+    assert (got - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
