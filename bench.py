@@ -338,7 +338,7 @@ def main():
         Y32 = eng.ggn_vp(V, scale, alpha)
         try:
             set_precision("bf16x3")
-            eng.ggn_vp(V, scale, alpha)
+            Ys0 = eng.ggn_vp(V, scale, alpha).clone()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(3):
@@ -349,6 +349,7 @@ def main():
             set_precision("f32")
         split_line = dict(value=P / t_s, unit="GGN-vp/s", ms_per_step=1e3 * t_s, dtype="bf16x3",
                           rel_diff_vs_f32=float(((Ys - Y32).abs().max() / Y32.abs().max()).item()),
+                          run_to_run=float(((Ys - Ys0).abs().max() / Y32.abs().max()).item()),
                           note="opt-in lip_set_precision(1): operands split hi+lo in bf16, 3 bf16 MFMAs per product, "
                                "f32 accumulate (implicit-GEMM and weight-gradient kernels); NOT the headline: the default is exact f32")
 
@@ -461,7 +462,28 @@ def main():
                                               "sweeps over 2 images at 224 x 224, then O(d) per Adam step")
         from lip_amd.ggn import clear_engine_cache
         clear_engine_cache()
-        del Zl, st50d
+        # one gradient step of the inducing-point objective at this scale (configs[4]; src/train_inducing.py:195-232):
+        # the reference's stochastic Hutch++ / SLQ estimate differentiated matrix-free (stochastic_grad.py) — a factor
+        # of the data batch would be 8 x 1000 rows of 25.6 M floats (819 GB); here the batch enters through products
+        # with the data precision only
+        from lip_amd.train_inducing import variational_grad_stochastic
+        Xg50 = torch.rand(8, 224, 224, 3, generator=torch.Generator().manual_seed(7)).to(dev)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        t1 = time.perf_counter()
+        v50, g50, i50 = variational_grad_stochastic(Zl, Xg50, st50d, 1.0, key=3, model_type="classifier", full_set_size=10000,
+                                                    st_samples=48, slq_samples=2, slq_num_matvecs=4, return_terms=True)
+        torch.cuda.synchronize()
+        r50_line["inducing_gradient_step"] = dict(
+            seconds=time.perf_counter() - t1, inducing_images=2, data_images=8, K=1000, d=2000, st_samples=48, slq_samples=2,
+            slq_num_matvecs=4, rank_one_directions=i50["directions"], value=v50, grad_norm=float(g50.norm().item()),
+            grad_finite=bool(torch.isfinite(g50).all().item()), peak_memory_GiB=torch.cuda.max_memory_allocated() / 2 ** 30,
+            note="value and exact gradient of alternative_objective_scalable's estimate on fixed probes (what "
+                 "jax.value_and_grad returns, src/train_inducing.py:196): adjoint of Hutch++ (QR included) and of the "
+                 "Golub-Kahan SLQ, 2 (2 s1 + s2) products with the data precision, a matrix-free 2000 x 2000 Gram, one "
+                 "shared-direction second-order pass; includes binding both engines")
+        clear_engine_cache()
+        del Zl, st50d, Xg50, g50
         torch.cuda.empty_cache()
 
     # ---- the north star's Krylov route: D-space Lanczos on the matrix-free GGN + alpha I (36 matvecs, full re-orth.) ----
@@ -525,7 +547,20 @@ def main():
         _input_grad_of_pairing(st_g, Zg, Mg, "classifier")
         torch.cuda.synchronize()
         t_so = time.perf_counter() - t1
+        # the reference's own (stochastic) quantity at its defaults: 256 probes (s1 = 240, s2 = 16), 2 x 40-step SLQ
+        t1 = time.perf_counter()
+        loss_s, gZs, info_s = variational_grad_scalable(Zg, Xg, st_g, alpha, key=5, model_type="classifier", full_set_size=full,
+                                                        method="stochastic", st_samples=256, slq_samples=2, return_terms=True)
+        torch.cuda.synchronize()
+        t_gs = time.perf_counter() - t1
         ipgrad_line = dict(seconds_per_step=t_g, second_order_pass_seconds=t_so, loss=loss_g,
+                           stochastic=dict(seconds_per_step=t_gs, st_samples=256, slq_samples=2, slq_num_matvecs=int(n * 0.8),
+                                           rank_one_directions=info_s["directions"], value=loss_s,
+                                           grad_finite=bool(torch.isfinite(gZs).all().item()),
+                                           cosine_to_exact_gradient=float((gZs.double() * gZ.double()).sum() /
+                                                                          (gZs.double().norm() * gZ.double().norm())),
+                                           note="method='stochastic': value and exact gradient of the Hutch++ / SLQ estimate on "
+                                                "fixed probes (src/train_inducing.py:196), matrix-free"),
                            grad_finite=bool(torch.isfinite(gZ).all().item()), inducing_images=n, data_batch=256,
                            note="value and gradient of the exact KL objective the reference's Hutch++ / SLQ estimators target; "
                                 "no torch.func: the input derivative of the parameter-JVP pairing is reverse mode over the "

@@ -180,7 +180,7 @@ def variational_grad_scalable(Z, X, state, alpha, key=None, model_type="classifi
     if method != "stochastic":
         raise ValueError("method must be 'auto', 'exact' or 'stochastic'")
     skw = {k: v for k, v in kw.items() if k in ("st_samples", "slq_samples", "slq_num_matvecs", "logdet_beta", "probes",
-                                                 "example_chunk", "max_directions")}
+                                                 "example_chunk", "max_directions", "return_terms")}
     return variational_grad_stochastic(Z, X, state, alpha, key=key, model_type=model_type, full_set_size=full_set_size, **skw)
 
 
