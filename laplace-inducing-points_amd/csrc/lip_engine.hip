@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "lip_internal.h"
 
@@ -56,6 +57,10 @@ struct RunCtx {
   float head_c;
   hipStream_t st;
   bool rows = false;   // lip_vjp_rows: Y holds one row per (probe, example); no reduction crosses examples
+  // summed products (lip_ggn_vp / lip_vjp): a weight gradient that reduces all rows in one block may WRITE
+  // y = s acc + alpha v instead of adding to an initialised block (the initialisation then skips its parameters)
+  bool fuse = false;
+  float alpha = 0.f;
 };
 
 inline float* resolve(const RunCtx& c, const lip_ref_t& r) {
@@ -99,6 +104,37 @@ int rows_reduce(const RunCtx& c, const float* out, long long out_ps, int n_img, 
 int check_space(const RunCtx& c, const lip_ref_t& r, const char* what) {
   if (r.space == LIP_SP_NONE) return LIP_OK;
   if (resolve(c, r) == nullptr) { set_error("op operand '%s' refers to an unbound space %d", what, r.space); return LIP_ERR_STATE; }
+  return LIP_OK;
+}
+
+// resolved parameter block of a WGRAD op in this context (also queried by the initialisation plan of lip_ggn_vp / lip_vjp)
+int make_wgrad(const RunCtx& c, const lip_op_t& op, WgradP& p) {
+  const lip_seg_t& g = op.seg[0];
+  p = WgradP();
+  p.a = resolve(c, g.a);
+  p.IH = g.IH; p.IW = g.IW; p.C = g.C; p.KH = g.KH; p.KW = g.KW;
+  p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
+  p.g = resolve(c, g.b); p.g_ps = g.b.pstride;
+  p.R = op.n_img * op.OH * op.OW; p.OHW = op.OH * op.OW; p.OW = op.OW; p.N = op.N;
+  p.M = g.KH * g.KW * g.C;
+  if (op.OH <= 0 || op.OW <= 0) { set_error("WGRAD: bad geometry"); return LIP_ERR_ARG; }
+  p.dOHW = FastDiv((unsigned)p.OHW); p.dOW = FastDiv((unsigned)p.OW);
+  p.y = resolve(c, op.out); p.y_ps = op.out.pstride;
+  p.scale = resolve(c, op.scale);
+  p.ksplit = op.ksplit > 0 ? op.ksplit : 0;           // 0: the launcher picks the row split for the probe count
+  if (c.rows) {
+    p.ksplit = op.n_img; p.seg_rows = p.OHW; p.seg_ys = p.y_ps; p.y_ps *= op.n_img;
+  }
+  if (!p.a || !p.g || !p.y || p.R <= 0 || p.N <= 0 || p.M <= 0) { set_error("WGRAD: bad operands"); return LIP_ERR_ARG; }
+  if ((long long)p.R * p.N >= (1ll << 31) || (long long)op.n_img * p.IH * p.IW * p.C >= (1ll << 31) || (long long)p.M * p.N >= (1ll << 31)) {
+    set_error("WGRAD: a tensor of this binding has 2^31 or more elements; bind fewer examples per engine (ExampleChunkedGGN)");
+    return LIP_ERR_ARG;
+  }
+  if ((p.C & 3) == 0 && (((uintptr_t)p.a) & 15)) { set_error("WGRAD: activations not 16-byte aligned"); return LIP_ERR_ARG; }
+  if (c.fuse && !c.rows && op.out.space == LIP_SP_YOUT && wgrad_will_overwrite(p, c.P)) {
+    p.overwrite = 1;
+    p.v = c.V ? c.V + op.out.off : nullptr; p.v_ps = op.out.pstride; p.alpha = c.alpha;
+  }
   return LIP_OK;
 }
 
@@ -159,28 +195,9 @@ int run_op(const RunCtx& c, const lip_op_t& op) {
       return LIP_OK;
     }
     case LIP_OP_WGRAD: {
-      const lip_seg_t& g = op.seg[0];
-      WgradP p = WgradP();
-      p.a = resolve(c, g.a);
-      p.IH = g.IH; p.IW = g.IW; p.C = g.C; p.KH = g.KH; p.KW = g.KW;
-      p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
-      p.g = resolve(c, g.b); p.g_ps = g.b.pstride;
-      p.R = op.n_img * op.OH * op.OW; p.OHW = op.OH * op.OW; p.OW = op.OW; p.N = op.N;
-      p.M = g.KH * g.KW * g.C;
-      if (op.OH <= 0 || op.OW <= 0) { set_error("WGRAD: bad geometry"); return LIP_ERR_ARG; }
-      p.dOHW = FastDiv((unsigned)p.OHW); p.dOW = FastDiv((unsigned)p.OW);
-      p.y = resolve(c, op.out); p.y_ps = op.out.pstride;
-      p.scale = resolve(c, op.scale);
-      p.ksplit = op.ksplit > 0 ? op.ksplit : 0;           // 0: the launcher picks the row split for the probe count
-      if (c.rows) {
-        p.ksplit = op.n_img; p.seg_rows = p.OHW; p.seg_ys = p.y_ps; p.y_ps *= op.n_img;
-      }
-      if (!p.a || !p.g || !p.y || p.R <= 0 || p.N <= 0 || p.M <= 0) { set_error("WGRAD: bad operands"); return LIP_ERR_ARG; }
-      if ((long long)p.R * p.N >= (1ll << 31) || (long long)op.n_img * p.IH * p.IW * p.C >= (1ll << 31) || (long long)p.M * p.N >= (1ll << 31)) {
-        set_error("WGRAD: a tensor of this binding has 2^31 or more elements; bind fewer examples per engine (ExampleChunkedGGN)");
-        return LIP_ERR_ARG;
-      }
-      if ((p.C & 3) == 0 && (((uintptr_t)p.a) & 15)) { set_error("WGRAD: activations not 16-byte aligned"); return LIP_ERR_ARG; }
+      WgradP p;
+      const int rc = make_wgrad(c, op, p);
+      if (rc) return rc;
       RUN_CHECK(launch_wgrad(p, c.P, c.st), "wgrad launch");
       return LIP_OK;
     }
@@ -326,6 +343,35 @@ int run_tape(const RunCtx& c, int which, bool skip_head) {
   return LIP_OK;
 }
 
+// Initialise the (pc, D) output block of a summed product: alpha * V (or 0) everywhere EXCEPT the parameters a fused
+// weight gradient of the backward tape will write outright (make_wgrad sets overwrite for exactly those ops).
+int init_output(const RunCtx& c, int64_t D) {
+  struct Range { int64_t off, len; };
+  std::vector<Range> skip;
+  for (const lip_op_t& op : c.e->tape[LIP_TAPE_BACKWARD]) {
+    if (op.kind != LIP_OP_WGRAD) continue;
+    WgradP p;
+    const int rc = make_wgrad(c, op, p);
+    if (rc) return rc;
+    if (p.overwrite) skip.push_back({op.out.off, (int64_t)p.M * p.N});
+  }
+  const float* v = c.alpha != 0.f ? c.V : nullptr;
+  if (skip.empty()) {
+    if (v) RUN_CHECK(launch_scale_copy(c.Y, v, c.alpha, (long long)c.P * D, c.st), "scale_copy");
+    else RUN_CHECK(hipMemsetAsync(c.Y, 0, sizeof(float) * (size_t)c.P * D, c.st), "memset Y");
+    return LIP_OK;
+  }
+  std::sort(skip.begin(), skip.end(), [](const Range& a, const Range& b) { return a.off < b.off; });
+  int64_t pos = 0;
+  for (const Range& r : skip) {
+    if (r.off < pos) { set_error("init_output: overlapping weight-gradient outputs"); return LIP_ERR_STATE; }
+    RUN_CHECK(launch_scale_copy_range(c.Y, v, c.alpha, pos, r.off - pos, c.P, D, c.st), "scale_copy_range");
+    pos = r.off + r.len;
+  }
+  RUN_CHECK(launch_scale_copy_range(c.Y, v, c.alpha, pos, D - pos, c.P, D, c.st), "scale_copy_range");
+  return LIP_OK;
+}
+
 int ready(const lip_engine* e, const char* who) {
   if (!e) { set_error("%s: null engine", who); return LIP_ERR_ARG; }
   if (!e->theta || !e->prim || !e->work || e->max_chunk <= 0) { set_error("%s: engine not bound", who); return LIP_ERR_STATE; }
@@ -444,9 +490,9 @@ int lip_ggn_vp(lip_engine_t* e, const float* V, float* Y, int32_t P, float scale
     const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
     const float* v = V + (int64_t)c0 * e->D;
     float* y = Y + (int64_t)c0 * e->D;
-    if (alpha != 0.f) RUN_CHECK(launch_scale_copy(y, v, alpha, (long long)pc * e->D, st), "scale_copy");
-    else RUN_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)pc * e->D, st), "memset Y");
     RunCtx c{e, v, y, nullptr, pc, LIP_HEAD_GGN, scale, st};
+    c.fuse = true; c.alpha = alpha;
+    if ((rc = init_output(c, e->D))) return rc;
     if ((rc = run_tape(c, LIP_TAPE_TANGENT, false))) return rc;
     if ((rc = run_tape(c, LIP_TAPE_BACKWARD, true))) return rc;
   }
@@ -475,8 +521,9 @@ int lip_vjp(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_m
   for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
     const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
     float* y = Y + (int64_t)c0 * e->D;
-    RUN_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)pc * e->D, st), "memset Y");
     RunCtx c{e, nullptr, y, const_cast<float*>(U) + (int64_t)c0 * hstride, pc, head_mode, cc, st};
+    c.fuse = true; c.alpha = 0.f;
+    if ((rc = init_output(c, e->D))) return rc;
     if ((rc = run_tape(c, LIP_TAPE_BACKWARD, false))) return rc;
   }
   return LIP_OK;

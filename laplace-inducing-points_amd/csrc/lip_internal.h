@@ -79,6 +79,11 @@ struct WgradP {
   // per-example rows (lip_vjp_rows): grid.z = example, the row reduction of block z covers only that example's
   // seg_rows = OH*OW rows and lands in Y row (p, z): y + p*y_ps + z*seg_ys
   int seg_rows; long long seg_ys;
+  // fused output of a weight gradient whose launch reduces all R rows in one block (no row split):
+  //   overwrite == 1:  y = s * acc + alpha * v     (v = the probe's own slice of V at the same offset, or null)
+  // instead of y += s * acc on a block the caller initialised with alpha * V — the initialisation pass over these
+  // parameters is then skipped (lip_ggn_vp).  Set by the engine only where wgrad_will_overwrite() says so.
+  int overwrite; const float* v; long long v_ps; float alpha;
 };
 
 struct ReduceP {
@@ -141,6 +146,11 @@ hipError_t launch_head(const HeadP& p, int P, hipStream_t st);
 hipError_t launch_gemm_nt(const float* A, long long lda, int m, const float* B, long long ldb, int n, long long K, float* C,
                           hipStream_t st);
 hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st);
+// y[p][off + i] = a * x[p][off + i] (x null: 0) for i < len, p < P, row stride ld: the parameters a fused weight gradient
+// does NOT write (biases, BN parameters, layers on the accumulate path)
+hipError_t launch_scale_copy_range(float* y, const float* x, float a, long long off, long long len, int P, long long ld, hipStream_t st);
+// true when launch_wgrad(p, P) will run the one-block-per-tile kernel that honours WgradP::overwrite
+bool wgrad_will_overwrite(const WgradP& p, int P);
 
 void set_error(const char* fmt, ...);
 int precision_mode();

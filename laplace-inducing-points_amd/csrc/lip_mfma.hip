@@ -1499,6 +1499,119 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
 }
 
 // ------------------------------------------------------------------------------------------
+// weight gradient of a DENSE layer with a short reduction (R = n examples <= 64: the layers of an MLP — BASELINE
+// configs[2] — and the final Dense of every net):  dW_p (M x N) = s * a^T g_p  is outer-product shaped, 2 R FLOP per
+// output element against 4 B written (+ 4 B of alpha V read): at R = 50 it sits on the machine balance, and what the
+// tiled kernels above spend per block (LDS staging, barriers, a read-modify-write epilogue behind a 4-tile K loop)
+// left it at 1.8 TB/s.  Here nothing is staged: a wave keeps the A operand of its TM x 32 rows of M for ALL R rows in
+// registers (a[r][m]: lane (i = m, k = r & 1) of k-step r >> 1 — one coalesced dword per k-step, loaded once per wave,
+// the activations are shared by the probes), walks over (probe, 32-column tile) items, reads the B operand
+// g_p[r][n] straight into the MFMA operand registers (coalesced 128-B rows), and writes  y = s acc + alpha v  (overwrite)
+// or  y += s acc  (accumulate) with 128-B row segments.  No LDS, no barrier, R need not be padded beyond a multiple of 2.
+// ------------------------------------------------------------------------------------------
+template <int TM, int KK>
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(const WgradP prm) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: the item loop below is wave-uniform (as a VGPR value it
+                                                                 // made the loop divergent: both store paths under exec masks, 64-bit per-lane addresses)
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int N = prm.N, M = prm.M, R = prm.R;
+  const int m0 = (int)blockIdx.y * (32 * TM);
+  // Every load is unconditional on a CLAMPED index (a conditional load costs a branch and a full s_waitcnt per
+  // element: 64 serial round trips per item in the first version of this kernel, 0.45 ms for the 784 x 1024 layer
+  // against 0.23 ms of the tiled kernel).  Row i of the output depends on row i of A only and column j on column j
+  // of B only, so rows >= M and columns >= N may hold anything (they are never stored); only the reduction rows
+  // r >= R must not contribute: A is zeroed there, B reads a valid row instead.
+  float areg[TM][KK];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = min(m0 + 32 * tm + l31, M - 1);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const int r = 2 * kk + lh;
+      const float t = prm.a[(unsigned)(min(r, R - 1) * M + m)];
+      areg[tm][kk] = r < R ? t : 0.f;
+    }
+  }
+  const int tiles_n = (N + 31) / 32;
+  const int total = prm.P * tiles_n;                            // (probe, column tile) items; < 2^31 (host-checked)
+  const bool over = prm.overwrite != 0;
+  const bool rows_full = m0 + 32 * TM <= M;
+  const float sa = over ? prm.alpha : 1.f;
+  const unsigned last = (unsigned)(M * N - 1);
+  for (int ct = (int)blockIdx.x * 4 + wave; ct < total; ct += (int)gridDim.x * 4) {
+    const int p = ct / tiles_n;
+    const int n0 = (ct - p * tiles_n) * 32;
+    const int col = n0 + l31;
+    const bool cv = col < N;
+    const int colc = min(col, N - 1);
+    const float* __restrict__ gp = prm.g + (long long)p * prm.g_ps;
+    float b[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) b[kk] = gp[(unsigned)(min(2 * kk + lh, R - 1) * N + colc)];
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[tm][q] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tm][kk], b[kk], acc[tm], 0, 0, 0);
+    const float sc = prm.scale ? prm.scale[colc] : 1.f;
+    float* __restrict__ yb = prm.y + (long long)p * prm.y_ps;
+    // what is added to s * acc: alpha * v (overwrite; v may be absent) or the block's current content (accumulate)
+    const float* __restrict__ src = over ? (prm.v ? prm.v + (long long)p * prm.v_ps : nullptr) : yb;
+    const bool full = rows_full && n0 + 32 <= N;               // uniform over the wave
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int mb = m0 + 32 * tm + 4 * lh;
+      const unsigned base = (unsigned)(mb * N + col);
+      float add[16];
+      if (src) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) add[q] = sa * src[min(base + (unsigned)(((q & 3) + 8 * (q >> 2)) * N), last)];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) add[q] = 0.f;
+      }
+      if (full) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) yb[base + (unsigned)(((q & 3) + 8 * (q >> 2)) * N)] = acc[tm][q] * sc + add[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (cv && mb + (q & 3) + 8 * (q >> 2) < M) yb[base + (unsigned)(((q & 3) + 8 * (q >> 2)) * N)] = acc[tm][q] * sc + add[q];
+      }
+    }
+  }
+}
+
+static int cu_count();
+
+static bool wgrad_skinny_ok(const WgradP& p) {
+  static const bool off = getenv("LIP_NOSKINNY") != nullptr || getenv("LIP_GENERIC") != nullptr;       // A/B switch
+  return !off && precision_mode() == 0 && p.seg_rows == 0 && p.ksplit <= 1 && p.R <= 64 && p.OHW == 1 && p.pad_h == 0 &&
+         p.pad_w == 0 && p.KH == p.IH && p.KW == p.IW && (long long)p.R * p.M < (1ll << 31) && p.M >= 32 && p.N <= (1 << 20);
+}
+
+bool wgrad_will_overwrite(const WgradP& p, int P) { (void)P; return wgrad_skinny_ok(p); }
+
+template <int TM, int KK>
+static hipError_t run_wgrad_skinny(const WgradP& p0, int P, hipStream_t st) {
+  WgradP p = p0;
+  p.P = P;
+  const int mgroups = (p.M + 32 * TM - 1) / (32 * TM);
+  const long long items = (long long)P * ((p.N + 31) / 32);                  // (probe, column tile) items, 4 per block and trip
+  long long gx = (2ll * 4 * cu_count() / 4 + mgroups - 1) / mgroups;         // ~2 waves per SIMD over the chip
+  gx = (gx + 7) / 8 * 8;                                                     // the m-groups of one column range share an XCD (their B rows an L2)
+  if (gx > (items + 3) / 4) gx = (items + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((wgrad_skinny_kernel<TM, KK>), dim3((unsigned)gx, (unsigned)mgroups), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // C (m, n) += A B^T for A (m, K), B (n, K) float32 with K-contiguous rows and K >> m, n (K = D ~ 1e6): the tall-skinny
 // products of the posterior engine on a materialised factor — W^T applied to a block of draws (src/sample.py:130-139),
 // the first GEMM of the factor-mode GGN-vp.  Both operands run along K in memory, i.e. both need the transposing
@@ -1926,6 +2039,12 @@ static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
 }
 
 hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
+  if (wgrad_skinny_ok(p)) {
+    if (p.R <= 16) return run_wgrad_skinny<4, 8>(p, P, st);
+    if (p.R <= 52) return run_wgrad_skinny<4, 26>(p, P, st);
+    return run_wgrad_skinny<2, 32>(p, P, st);
+  }
+  if (p.overwrite) return hipErrorInvalidValue;       // the engine asks for it only where wgrad_will_overwrite() holds
   static const bool nopb = getenv("LIP_NOPB") != nullptr || getenv("LIP_GENERIC") != nullptr;   // A/B switch
   const bool pb_ok = !nopb && P > 1 && p.N <= 64 && (p.N & 3) == 0 && p.M >= 96 && (p.g_ps & 3) == 0 && (((uintptr_t)p.g) & 15) == 0 && (p.C & 3) == 0 && (((uintptr_t)p.a) & 15) == 0 &&
                      (long long)(P - 1) * p.g_ps + (long long)p.R * p.N < (1ll << 32);

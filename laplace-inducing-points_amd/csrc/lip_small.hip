@@ -370,6 +370,20 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(float* y, const float* 
     y[idx] = a * x[idx];
 }
 
+__global__ void scale_copy_range_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long long off, long long len,
+                                        long long ld) {
+  const long long base = (long long)blockIdx.y * ld + off;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+    y[base + i] = x ? a * x[base + i] : 0.f;
+}
+
+hipError_t launch_scale_copy_range(float* y, const float* x, float a, long long off, long long len, int P, long long ld, hipStream_t st) {
+  if (len <= 0 || P <= 0) return hipSuccess;
+  const long long blocks = (len + 255) / 256;
+  hipLaunchKernelGGL(scale_copy_range_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024), (unsigned)P), dim3(256), 0, st, y, x, a, off, len, ld);
+  return hipGetLastError();
+}
+
 hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st) {
   const long long blocks = (count + 255) / 256;
   hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, y, x, a, count);

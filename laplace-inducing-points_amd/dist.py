@@ -35,8 +35,42 @@ class ShardedDataSum:
     1543 / 1490 GGN-vp/s at 256 / 128 / 64 probes), so a large first and a small last chunk beat equal ones."""
 
     def __init__(self, local: Callable[..., torch.Tensor], alpha: float = 0.0,
-                 group: Optional[dist.ProcessGroup] = None, chunk=None):
+                 group: Optional[dist.ProcessGroup] = None, chunk=None, profile: bool = False):
         self.local, self.alpha, self.group, self.chunk = local, float(alpha), group, chunk
+        # profile: per call, the bytes handed to the all-reduce and the time the compute stream spends waiting for
+        # collectives it could not hide (events around the waits on the GPU, wall clock on the CPU) -> self.stats
+        self.profile = profile
+        self.stats = dict(calls=0, allreduce_bytes=0, exposed_wait_ms=0.0)
+        self._pending_events = []
+
+    def _tic(self, ref: torch.Tensor):
+        if not self.profile:
+            return None
+        if ref.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def _toc(self, t0, ref: torch.Tensor):
+        if t0 is None:
+            return
+        if ref.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._pending_events.append((t0, e))         # read lazily: no synchronisation inside the matvec
+        else:
+            import time
+            self.stats["exposed_wait_ms"] += 1e3 * (time.perf_counter() - t0)
+
+    def read_stats(self):
+        """Totals since construction (synchronises the events recorded so far)."""
+        for a, b in self._pending_events:
+            b.synchronize()
+            self.stats["exposed_wait_ms"] += a.elapsed_time(b)
+        self._pending_events = []
+        return dict(self.stats)
 
     def _bounds(self, P: int):
         if isinstance(self.chunk, (tuple, list)):
@@ -61,12 +95,19 @@ class ShardedDataSum:
             for c0, c1 in self._bounds(V.shape[0]):
                 self.local(V[c0:c1], out=Y[c0:c1])
                 pending.append(dist.all_reduce(Y[c0:c1], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            t0 = self._tic(Y)
             for h in pending:
                 h.wait()
+            self._toc(t0, Y)
         else:
             Y = self.local(V)
             if world > 1:
+                t0 = self._tic(Y)
                 dist.all_reduce(Y, op=dist.ReduceOp.SUM, group=self.group)      # the one collective per matvec
+                self._toc(t0, Y)
+        if self.profile and world > 1:
+            self.stats["calls"] += 1
+            self.stats["allreduce_bytes"] += Y.numel() * Y.element_size()
         if self.alpha != 0.0:
             Y = Y.add_(V.reshape(Y.shape), alpha=self.alpha) if Y.is_cuda else Y + self.alpha * V.reshape(Y.shape)
         return Y

@@ -13,6 +13,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "resnet50":
     P = 64
     net = ResNet50(1000); st = create_state(net, seed=1, dtype=torch.float32)
     eng = LinearizedNet(st, torch.rand(8, 224, 224, 3).cuda(), "classifier", workspace_bytes=64 << 30, max_chunk=P)
+elif len(sys.argv) > 1 and sys.argv[1] == "mlp":          # BASELINE configs[2]: MNIST-MLP 784-1024-512-256-128-10, n = 50, P = 64
+    from lip_amd.scalemodels import LargeClassifier
+    P = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    net = LargeClassifier((28, 28, 1), [1024, 512, 256, 128], 4, 10); st = create_state(net, seed=12345, dtype=torch.float32)
+    eng = LinearizedNet(st, torch.rand(50, 28, 28, 1).cuda(), "classifier", workspace_bytes=2 << 30, max_chunk=P)
 else:
     P = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     net = ResNet1M(10); st = create_state(net, seed=1, dtype=torch.float32)
@@ -23,10 +28,13 @@ eng.ggn_vp(V, 1.0, 0.0); torch.cuda.synchronize()
 rows = []
 for which in (1, 2):
     for i, op in enumerate(eng.cn.tapes[which]):
-        if op.kind not in (nv.OP_IGEMM, nv.OP_WGRAD):
-            continue
         R = op.n_img * op.OH * op.OW
-        if op.kind == nv.OP_IGEMM:
+        if op.kind not in (nv.OP_IGEMM, nv.OP_WGRAD):
+            if len(sys.argv) > 1 and sys.argv[1] == "mlp":
+                fl = 0; name = f"kind {op.kind} R={R} N={op.N}"
+            else:
+                continue
+        elif op.kind == nv.OP_IGEMM:
             fl = 0; desc = []
             for q in range(op.nseg):
                 sg = op.seg[q]
@@ -50,3 +58,12 @@ tot = sum(r[3] for r in rows)
 for which, i, name, ms, tf in rows:
     print(f"t{which} op{i:3d} {ms:7.3f} ms {tf:6.1f} TF  {name}")
 print("total ms", tot)
+# whole product (fused alpha where the weight gradients allow it)
+for al in (0.0, 1e-3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eng.ggn_vp(V, 1.0, al)
+    e0.record()
+    for _ in range(10):
+        eng.ggn_vp(V, 1.0, al)
+    e1.record(); torch.cuda.synchronize()
+    print(f"ggn_vp alpha={al}: {e0.elapsed_time(e1) / 10:.3f} ms per {P}-probe block")

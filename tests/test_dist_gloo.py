@@ -73,7 +73,29 @@ def _worker(rank, world, port, ret):
         err3 += 1.0
     except ValueError:
         pass
-    ret[rank] = (err, err2 + err3)
+    # Krylov consumers driven by the sharded data sum (one all-reduce per matvec inside every iteration): Lanczos
+    # f(A) b (src/sample.py:113-126) and Hutch++ (src/stochtrace.py:118-135) — equal to the single-process answer and
+    # identical on every rank (all ranks must issue the same sequence of collectives)
+    from oracle.matfree import dense_funm_sym_eigh, funm_lanczos_sym, tridiag_sym
+    from oracle.stochtrace import hutchpp_v2
+    prof = ShardedDataSum(local, alpha, profile=True)
+    A_sh = lambda v: prof(v[None])[0]
+    A_full = lambda v: vp_full(v) + alpha * v
+    est = funm_lanczos_sym(dense_funm_sym_eigh(lambda x: x ** -0.5), tridiag_sym(12))
+    b = torch.randn(81, dtype=torch.float64, generator=g)
+    x_sh, x_full = est(A_sh, b), est(A_full, b)
+    err4 = (x_sh - x_full).abs().max().item() / x_full.abs().max().item()
+    hp = torch.sign(torch.randn(24, 81, dtype=torch.float64, generator=g))
+    t_sh = hutchpp_v2(A_sh, lambda _: hp, s1=8, s2=16)
+    t_full = hutchpp_v2(A_full, lambda _: hp, s1=8, s2=16)
+    err4 += abs(float(t_sh) - float(t_full)) / abs(float(t_full))
+    mine = torch.cat([x_sh, t_sh.reshape(1)])
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    err4 += max((o - mine).abs().max().item() for o in both)                 # rank-identical, bit for bit
+    st_ = prof.read_stats()
+    ok_stats = st_["calls"] == 12 + 2 * 8 + 16 and st_["allreduce_bytes"] == st_["calls"] * 81 * 8 and st_["exposed_wait_ms"] >= 0.0
+    ret[rank] = (err, err2 + err3, err4, ok_stats)
     dist.destroy_process_group()
 
 
@@ -84,9 +106,11 @@ def test_sharded_data_sum_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
-        err, err2 = ret[r]
+        err, err2, err4, ok_stats = ret[r]
         assert err < 1e-10, f"rank {r}: sharded GGN-vp differs by {err}"
         assert err2 < 1e-12, f"rank {r}: gathered W^T differs by {err2}"
+        assert err4 < 1e-9, f"rank {r}: Lanczos / Hutch++ over the sharded data sum differ by {err4}"
+        assert ok_stats, f"rank {r}: collective statistics (one all-reduce per matvec) are off"
 
 
 def test_shard_bounds_cover():
