@@ -84,6 +84,7 @@ struct WgradP {
   // instead of y += s * acc on a block the caller initialised with alpha * V — the initialisation pass over these
   // parameters is then skipped (lip_ggn_vp).  Set by the engine only where wgrad_will_overwrite() says so.
   int overwrite; const float* v; long long v_ps; float alpha;
+  int sk_mg0, sk_tiles, sk_tn0;         // wgrad_skinny_kernel: first m-group of the launch, column tiles per probe it walks, first of them
 };
 
 struct ReduceP {

@@ -1509,19 +1509,22 @@ __global__ __launch_bounds__(WM * WN * 64) void wgrad_fast_kernel(const WgradP p
 // g_p[r][n] straight into the MFMA operand registers (coalesced 128-B rows), and writes  y = s acc + alpha v  (overwrite)
 // or  y += s acc  (accumulate) with 128-B row segments.  No LDS, no barrier, R need not be padded beyond a multiple of 2.
 // ------------------------------------------------------------------------------------------
-template <int TM, int KK>
-__global__ __launch_bounds__(256) void wgrad_skinny_kernel(const WgradP prm) {
+// FULL: the interior — every (m-group, column tile) item is complete, all indices are affine in (lane, element), no
+// clamps, unconditional stores, software pipelined.  !FULL: the same items of the partial last m-group / last column
+// tile with clamped loads and masked stores (the interior items are skipped there).
+template <int TM, int KK, bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_skinny_kernel(const WgradP prm) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: the item loop below is wave-uniform (as a VGPR value it
                                                                  // made the loop divergent: both store paths under exec masks, 64-bit per-lane addresses)
   const int l31 = lane & 31, lh = lane >> 5;
   const int N = prm.N, M = prm.M, R = prm.R;
-  const int m0 = (int)blockIdx.y * (32 * TM);
-  // Every load is unconditional on a CLAMPED index (a conditional load costs a branch and a full s_waitcnt per
-  // element: 64 serial round trips per item in the first version of this kernel, 0.45 ms for the 784 x 1024 layer
-  // against 0.23 ms of the tiled kernel).  Row i of the output depends on row i of A only and column j on column j
-  // of B only, so rows >= M and columns >= N may hold anything (they are never stored); only the reduction rows
-  // r >= R must not contribute: A is zeroed there, B reads a valid row instead.
+  const int m0 = ((int)blockIdx.y + prm.sk_mg0) * (32 * TM);
+  // Loads are unconditional on CLAMPED indices where an index can leave its array (a conditional load costs a branch
+  // and a full s_waitcnt per element: 64 serial round trips per item in the first version of this kernel).  Row i of
+  // the output depends on row i of A only and column j on column j of B only, so rows >= M and columns >= N may hold
+  // anything (they are never stored); only the reduction rows r >= R must not contribute: A is zeroed there, B reads a
+  // valid row instead.
   float areg[TM][KK];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -1533,57 +1536,89 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const WgradP prm) {
       areg[tm][kk] = r < R ? t : 0.f;
     }
   }
-  const int tiles_n = (N + 31) / 32;
+  const int tiles_n = prm.sk_tiles;                             // column tiles per probe this launch walks: [sk_tn0, sk_tn0 + sk_tiles)
   const int total = prm.P * tiles_n;                            // (probe, column tile) items; < 2^31 (host-checked)
   const bool over = prm.overwrite != 0;
-  const bool rows_full = m0 + 32 * TM <= M;
   const float sa = over ? prm.alpha : 1.f;
   const unsigned last = (unsigned)(M * N - 1);
-  for (int ct = (int)blockIdx.x * 4 + wave; ct < total; ct += (int)gridDim.x * 4) {
+  const int stride = (int)gridDim.x * 4;
+  // B operand of k-step kk: rows (2 kk, 2 kk + 1) for the two lane halves.  Addressed as a wave-uniform row pointer
+  // (scalar registers) plus ONE per-lane offset — 26 per-lane row offsets would cost 26 VGPRs of a budget that has
+  // none to spare.  A k-step whose second row is past R reads row R - 1 (its A operand is zero there), one that is
+  // past R altogether reads row 0.
+  const unsigned lhN = (unsigned)(lh * N);
+  auto load_b = [&](int ct, float (&b)[KK]) {
     const int p = ct / tiles_n;
-    const int n0 = (ct - p * tiles_n) * 32;
-    const int col = n0 + l31;
-    const bool cv = col < N;
-    const int colc = min(col, N - 1);
-    const float* __restrict__ gp = prm.g + (long long)p * prm.g_ps;
-    float b[KK];
+    const unsigned colc = (unsigned)min((prm.sk_tn0 + ct - p * tiles_n) * 32 + l31, N - 1);
+    const unsigned pairc = colc + lhN;
+    const float* __restrict__ gp = prm.g + (long long)p * prm.g_ps;        // wave-uniform base
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) b[kk] = gp[(unsigned)(min(2 * kk + lh, R - 1) * N + colc)];
-    f32x16 acc[TM];
+    for (int kk = 0; kk < KK; ++kk) {
+      const bool pair = 2 * kk + 1 < R;                                    // uniform
+      const float* __restrict__ rowp = gp + (pair ? (long long)(2 * kk) * N : (2 * kk < R ? (long long)(R - 1) * N : 0ll));
+      b[kk] = rowp[pair ? pairc : colc];
+    }
+  };
+  unsigned ebase[TM];                                           // element offset of accumulator register 0 (column l31 of tile 0)
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[tm][q] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tm][kk], b[kk], acc[tm], 0, 0, 0);
-    const float sc = prm.scale ? prm.scale[colc] : 1.f;
-    float* __restrict__ yb = prm.y + (long long)p * prm.y_ps;
-    // what is added to s * acc: alpha * v (overwrite; v may be absent) or the block's current content (accumulate)
-    const float* __restrict__ src = over ? (prm.v ? prm.v + (long long)p * prm.v_ps : nullptr) : yb;
-    const bool full = rows_full && n0 + 32 <= N;               // uniform over the wave
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int mb = m0 + 32 * tm + 4 * lh;
-      const unsigned base = (unsigned)(mb * N + col);
-      float add[16];
+  for (int tm = 0; tm < TM; ++tm) ebase[tm] = (unsigned)((m0 + 32 * tm + 4 * lh) * N + l31);
+  int ct = (int)blockIdx.x * 4 + wave;
+  if (ct >= total) return;
+  float b[KK], bn[KK];
+  load_b(ct, b);
+  for (; ct < total; ct += stride) {
+    // software pipeline: the next item's B operand and this item's epilogue operand are requested BEFORE the MFMA
+    // block, so with two waves per SIMD the matrix pipe never waits for memory
+    load_b(min(ct + stride, total - 1), bn);
+    const int p = ct / tiles_n;
+    {
+      const int n0 = (prm.sk_tn0 + ct - p * tiles_n) * 32;
+      const float sc = prm.scale ? prm.scale[min(n0 + l31, N - 1)] : 1.f;
+      float* __restrict__ yb = prm.y + (long long)p * prm.y_ps;
+      // what is added to s * acc: alpha * v (overwrite; v may be absent) or the block's current content (accumulate)
+      const float* __restrict__ src = over ? (prm.v ? prm.v + (long long)p * prm.v_ps : nullptr) : yb;
+      float add[TM][16];
       if (src) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) add[q] = sa * src[min(base + (unsigned)(((q & 3) + 8 * (q >> 2)) * N), last)];
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            if (FULL) {
+              add[tm][q] = (src + (long long)((q & 3) + 8 * (q >> 2)) * N)[ebase[tm] + (unsigned)n0];    // uniform row pointer + lane offset
+            } else {
+              const unsigned e = ebase[tm] + (unsigned)n0 + (unsigned)(((q & 3) + 8 * (q >> 2)) * N);
+              add[tm][q] = src[min(e, last)];
+            }
+          }
       } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) add[q] = 0.f;
-      }
-      if (full) {
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) yb[base + (unsigned)(((q & 3) + 8 * (q >> 2)) * N)] = acc[tm][q] * sc + add[q];
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          if (cv && mb + (q & 3) + 8 * (q >> 2) < M) yb[base + (unsigned)(((q & 3) + 8 * (q >> 2)) * N)] = acc[tm][q] * sc + add[q];
+          for (int q = 0; q < 16; ++q) add[tm][q] = 0.f;
       }
+      f32x16 acc[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[tm][q] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tm][kk], b[kk], acc[tm], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          if (FULL) {
+            (yb + (long long)((q & 3) + 8 * (q >> 2)) * N)[ebase[tm] + (unsigned)n0] = acc[tm][q] * sc + sa * add[tm][q];
+          } else {
+            const unsigned e = ebase[tm] + (unsigned)n0 + (unsigned)(((q & 3) + 8 * (q >> 2)) * N);
+            if (n0 + l31 < N && m0 + 32 * tm + 4 * lh + (q & 3) + 8 * (q >> 2) < M) yb[e] = acc[tm][q] * sc + sa * add[tm][q];
+          }
+        }
     }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) b[kk] = bn[kk];
   }
 }
 
@@ -1602,12 +1637,30 @@ static hipError_t run_wgrad_skinny(const WgradP& p0, int P, hipStream_t st) {
   WgradP p = p0;
   p.P = P;
   const int mgroups = (p.M + 32 * TM - 1) / (32 * TM);
-  const long long items = (long long)P * ((p.N + 31) / 32);                  // (probe, column tile) items, 4 per block and trip
-  long long gx = (2ll * 4 * cu_count() / 4 + mgroups - 1) / mgroups;         // ~2 waves per SIMD over the chip
-  gx = (gx + 7) / 8 * 8;                                                     // the m-groups of one column range share an XCD (their B rows an L2)
-  if (gx > (items + 3) / 4) gx = (items + 3) / 4;
-  if (gx < 1) gx = 1;
-  hipLaunchKernelGGL((wgrad_skinny_kernel<TM, KK>), dim3((unsigned)gx, (unsigned)mgroups), dim3(256), 0, st, p);
+  // interior (complete m-groups x complete column tiles), then the two strips with masked stores: the partial last
+  // m-group over all column tiles, and the partial last column tile of the complete m-groups (disjoint outputs)
+  const int mg_full = p.M / (32 * TM), tn_full = p.N / 32, tn_all = (p.N + 31) / 32;
+  // ONE round of resident waves per launch (2 per SIMD = 2 blocks per CU): the items are split statically over the
+  // waves, so a grid of 1.1 rounds takes two (measured: 2304 waves on 2048 slots, 0.195 ms; the 16-m-group layer at
+  // exactly 2048: 0.085 -> 0.070 with this rule)
+  auto grid_x = [&](long long its, int mg) {
+    long long g = 2ll * cu_count() / (mg > 0 ? mg : 1);
+    g = g >= 8 ? g / 8 * 8 : g;                                // the m-groups of one column range share an XCD (their B rows an L2)
+    if (g > (its + 3) / 4) g = (its + 3) / 4;
+    return (unsigned)(g < 1 ? 1 : g);
+  };
+  if (mg_full > 0 && tn_full > 0) {
+    p.sk_mg0 = 0; p.sk_tiles = tn_full; p.sk_tn0 = 0;
+    hipLaunchKernelGGL((wgrad_skinny_kernel<TM, KK, true>), dim3(grid_x((long long)P * tn_full, mg_full), (unsigned)mg_full), dim3(256), 0, st, p);
+  }
+  if (mg_full < mgroups) {
+    p.sk_mg0 = mg_full; p.sk_tiles = tn_all; p.sk_tn0 = 0;
+    hipLaunchKernelGGL((wgrad_skinny_kernel<TM, KK, false>), dim3(grid_x((long long)P * tn_all, 1), 1u), dim3(256), 0, st, p);
+  }
+  if (tn_full < tn_all && mg_full > 0) {
+    p.sk_mg0 = 0; p.sk_tiles = 1; p.sk_tn0 = tn_full;
+    hipLaunchKernelGGL((wgrad_skinny_kernel<TM, KK, false>), dim3(grid_x((long long)P, mg_full), (unsigned)mg_full), dim3(256), 0, st, p);
+  }
   return hipGetLastError();
 }
 
@@ -2040,8 +2093,8 @@ static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
 
 hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
   if (wgrad_skinny_ok(p)) {
-    if (p.R <= 16) return run_wgrad_skinny<4, 8>(p, P, st);
-    if (p.R <= 52) return run_wgrad_skinny<4, 26>(p, P, st);
+    if (p.R <= 16) return run_wgrad_skinny<2, 8>(p, P, st);
+    if (p.R <= 52) return run_wgrad_skinny<2, 26>(p, P, st);
     return run_wgrad_skinny<2, 32>(p, P, st);
   }
   if (p.overwrite) return hipErrorInvalidValue;       // the engine asks for it only where wgrad_will_overwrite() holds
