@@ -118,28 +118,58 @@ def spawn_ranks(n_ranks: int, argv) -> int:
         print(f"bench.py: --gpus {n_ranks} but only {ndev} GPU(s) visible; refusing to run fewer ranks than asked "
               "(LIP_DIST_BACKEND=gloo rehearses the N-rank path on the GPUs present)", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
+    import signal
+    procs = []
+
+    def _stop_children(grace=5.0):
+        """terminate, then kill, exactly the Popen children that are still alive (never a pattern)"""
+        alive = [pr for pr in procs if pr.poll() is None]
+        for pr in alive:
+            pr.terminate()
+        t_end = time.time() + grace
+        for pr in alive:
+            try:
+                pr.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+
+    def _on_signal(signum, frame):               # a killed parent must not leave ranks holding the GPUs
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old_handlers = {sg: signal.signal(sg, _on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    rc = 0
+    try:
+        # the rendezvous port: keep the probing socket OPEN (SO_REUSEADDR) until the children exist, so no other
+        # process can take the port between "found free" and rank 0's bind
+        sk = socket.socket()
+        sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.2)
-        for pr in list(live):
-            code = pr.poll()
-            if code is None:
-                continue
-            live.remove(pr)
-            if code != 0 and rc == 0:
-                rc = code
-                for other in live:               # exact PIDs of our own children, never a pattern
-                    other.terminate()
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdin=subprocess.DEVNULL, stdout=None if r == 0 else subprocess.DEVNULL))
+        sk.close()
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for pr in list(live):
+                code = pr.poll()
+                if code is None:
+                    continue
+                live.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in live:               # exact PIDs of our own children, never a pattern
+                        other.terminate()
+    except BaseException:
+        rc = rc or 130
+        raise
+    finally:
+        _stop_children()
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     return rc
 
 
@@ -153,6 +183,10 @@ def main():
     ap.add_argument("--samples", type=int, default=200, help="posterior samples for the samples/s line (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resnet50", action="store_true", help="skip the full-resolution ResNet-50 slice (configs[4])")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --n examples per GPU (the data set grows with N); strong: ONE data set of --n-total examples "
+                         "sharded over the ranks (configs[3] as written: a data batch sharded 8 ways)")
+    ap.add_argument("--n-total", type=int, default=2048, help="examples of the whole data set under --scaling strong")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -177,15 +211,33 @@ def main():
     net = ResNet1M(10)
     state = create_state(net, seed=1231231234, dtype=torch.float32)           # config/scale/resnet1_cifar10.yml:5
     g = torch.Generator().manual_seed(280300 + rank)                          # ip.seed (+rank: own data slice)
-    Z = torch.rand(args.n, 32, 32, 3, generator=g)
-    P, n, alpha, full = args.probes, args.n, 0.005, 49000
-    n_total = n * world
-    eng = LinearizedNet(state, Z.to(dev), "classifier", device=dev, workspace_bytes=24 << 30, max_chunk=P)
+    P, alpha, full = args.probes, 0.005, 49000
+    strong = args.scaling == "strong"
+    if strong:                                   # one data set of n_total examples, this rank's contiguous slice of it
+        args.samples, args.no_cpu_baseline = 0, True        # the secondary legs are defined on the 50-example weak config
+        from lip_amd.dist import shard_bounds
+        n_total = args.n_total
+        lo, hi = shard_bounds(n_total, world, rank)
+        n = hi - lo
+    else:
+        n = args.n
+        n_total = n * world
+    Z = torch.rand(n, 32, 32, 3, generator=g)
     scale = full / n_total
+    # this rank's binding for the headline bookkeeping (per-kernel profile, secondary legs): at most 50 examples
+    eng = LinearizedNet(state, Z[:min(n, 50)].to(dev), "classifier", device=dev, workspace_bytes=24 << 30, max_chunk=P)
+    if n > 64:
+        # a slice larger than one binding: example chunks of 50 behind one probe workspace (the data sum is associative)
+        from lip_amd.ggn import ExampleChunkedGGN
+        chunked = ExampleChunkedGGN(state.to(device=dev, dtype=torch.float32), Z.to(dev), "classifier", full_set_size=full,
+                                    example_chunk=50, workspace_bytes=24 << 30, max_probes=P)
+        chunked.scale = scale
+        local = lambda V, out=None: chunked(V, alpha / world, out=out)
+    else:
+        local = lambda V, out=None: eng.ggn_vp(V, scale, alpha / world, out=out)
     # alpha/world per rank sums to alpha*V in the all-reduce (no extra pass over the block); N > 1: the block is
     # swept as 3/4 + 1/4 of the probes, the all-reduce of the first part hides behind the sweep of the second
-    op = ShardedDataSum(lambda V, out=None: eng.ggn_vp(V, scale, alpha / world, out=out), 0.0,
-                        chunk=((0.75, 0.25) if world > 1 and P >= 64 else None))
+    op = ShardedDataSum(local, 0.0, chunk=((0.75, 0.25) if world > 1 and P >= 64 else None), profile=world > 1)
     V = krylov.fill_rademacher(P, eng.D, 1234, dev)
 
     def barrier():
@@ -209,6 +261,15 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = P * args.steps / dt                    # products over the WHOLE n_total-example set per second
     per_shard = value * world                      # products counted per 50-example shard (round-1 unit)
+    coll = None
+    if world > 1:                                  # what the timed steps (+ warm-up) handed to the collective, and what it cost
+        cs = op.read_stats()
+        coll = dict(allreduce_bytes_per_step=cs["allreduce_bytes"] / max(1, cs["calls"]),
+                    exposed_collective_ms_per_step=cs["exposed_wait_ms"] / max(1, cs["calls"]),
+                    ring_bytes_per_link_per_step=2.0 * (world - 1) / world * cs["allreduce_bytes"] / max(1, cs["calls"]),
+                    note="one all-reduce of the (P, D) float32 block per matvec, issued as 3/4 + 1/4 of the probes; the "
+                         "exposed time is what the compute stream waits for after its last launch (events around the waits), "
+                         "rank 0's view")
 
     # N > 1, secondary figure: the OTHER sharding north_star names — Hutchinson probes sharded, no data-path collective:
     # every rank sweeps its own block of P probes over a full 50-example set (the trace estimator then all-reduces P
@@ -218,7 +279,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            eng.ggn_vp(V, full / n, alpha)
+            eng.ggn_vp(V, full / eng.n, alpha)
         barrier()
         t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,7 +289,7 @@ def main():
     eng.profile(True)
     prof_steps = max(1, min(3, args.steps))
     for _ in range(prof_steps):
-        eng.ggn_vp(V, scale, alpha)
+        eng.ggn_vp(V, full / eng.n, alpha)
     prof = eng.profile_read()
     eng.profile(False)
     # one-off primal forward of the binding (reported separately; 2 MACs_fwd FLOP per example)
@@ -658,8 +719,10 @@ def main():
         line = dict(metric="GGN-vector products/sec", value=value, example_probe_products_per_s=value * n_total,
                     per_shard_products_per_s=per_shard, probe_sharded_products_per_s=probe_sharded,
                     unit="GGN-vp/s", n_gpus=world, steps=args.steps,
-                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
-                    scaling_note="weak scaling in the DATA sum: per-GPU work is fixed (50 examples x P probes), the data set "
+                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling=args.scaling, collective=coll,
+                    scaling_note=("strong scaling: ONE data set of %d examples, each rank sweeps its contiguous slice (chunks of "
+                                  "50 examples behind one probe workspace), one all-reduce per matvec; value = products over "
+                                  "the whole set per second" % n_total) if strong else "weak scaling in the DATA sum: per-GPU work is fixed (50 examples x P probes), the data set "
                                  "grows with N, so `value` (products over the whole set per second) stays flat when scaling "
                                  "is perfect — it is step time that should stay constant; the throughput that grows with N "
                                  "is example_probe_products_per_s (= value x 50 N); probe_sharded_products_per_s is the "

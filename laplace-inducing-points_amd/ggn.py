@@ -122,14 +122,16 @@ class ExampleChunkedGGN:
         self.engine = self.engines[0]
         self.n = n
 
-    def __call__(self, V, alpha: float = 0.0):
+    def __call__(self, V, alpha: float = 0.0, out: Optional[torch.Tensor] = None):
         single = V.dim() == 1
         Vb = V[None] if single else V
         Vb = Vb.to(device=self.engines[0].device, dtype=torch.float32).contiguous()
-        Y = self.engines[0].ggn_vp(Vb, self.scale, alpha)
-        tmp = torch.empty_like(Y) if len(self.engines) > 1 else None
-        for eng in self.engines[1:]:
-            Y += eng.ggn_vp(Vb, self.scale, 0.0, out=tmp)
+        Y = self.engines[0].ggn_vp(Vb, self.scale, alpha, out=out)
+        if len(self.engines) > 1:
+            if getattr(self, "_tmp", None) is None or self._tmp.shape != Y.shape:
+                self._tmp = torch.empty_like(Y)          # one scratch block for the chunks' partial products, kept
+            for eng in self.engines[1:]:
+                Y += eng.ggn_vp(Vb, self.scale, 0.0, out=self._tmp)
         return Y[0] if single else Y
 
     rows = __call__

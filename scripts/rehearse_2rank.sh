@@ -4,3 +4,5 @@
 export LIP_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 unset WORLD_SIZE RANK LOCAL_RANK
 timeout -k 10 400 python bench.py --gpus 2 --steps 2 --warmup 1 --probes 128 --samples 0 --no-cpu-baseline --no-resnet50
+# the same two ranks under strong scaling: ONE data set of 200 examples, 100 per rank as two chunks of 50
+timeout -k 10 400 python bench.py --gpus 2 --steps 2 --warmup 1 --probes 64 --scaling strong --n-total 200 --no-resnet50
