@@ -98,7 +98,8 @@ def predict_la_samples_dense(map_state, Xnew, Z, model_type, alpha, full_set_siz
 def predict_lla_scalable(map_state, Xnew, Z, model_type, alpha, key=None, full_set_size=None, num_samples=1, **sample_kw):
     """``src/lla.py:133-156``: f(x; theta_MAP) + J(x) w_s, w_s = sample(...)  -> (S, B, C).
     One engine is bound to the test batch; the S JVPs run as one tangent-forward block (the reference
-    maps them sequentially, ``:154``)."""
+    maps them sequentially, ``:154``).  ``sample_kw`` goes to :func:`sample` (``reference_compat=True`` for the
+    reference's clipped small-space Lanczos)."""
     flat_params, _ = flatten_nn_params(map_state.params)
     D = flat_params.shape[0]
     key = key if key is not None else 123                                       # :136

@@ -243,11 +243,23 @@ def _cached_parts(state, Z, D, alpha, model_type, full_set_size, clip_min, metho
     return parts
 
 
+def _compat(reference_compat: bool, clip_min, method):
+    """``reference_compat=True`` = the reference's own numerics in one switch: the monkey-patched eigenvalue clip
+    f(max(lambda, 1)) (``src/matfree_monkeypatch.py:19``) and the min(2M, d)-step small-space Lanczos
+    (``src/sample.py:113-115``) instead of the exact eigen-evaluation; ``solve(W^T W, .)`` (``:81-84``) is the
+    truncated pseudo-inverse here, identical wherever the Gram is invertible (where it is not — every classifier — the
+    reference's solve is ill-posed).  PARITY UNPINNED: no reference test that exercises the clip can pass
+    (SURVEY §4.1-7); checked against ``oracle/sample.py`` run with the same flags."""
+    return (REFERENCE_CLIP_MIN, "lanczos") if reference_compat else (clip_min, method)
+
+
 def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None, num_proj_steps=1,
-                   clip_min: Optional[float] = None, method: str = "eigh"):
+                   clip_min: Optional[float] = None, method: str = "eigh", reference_compat: bool = False):
     """``src/sample.py:55-145``.  Returns a block operator v -> A^(-1/2) v on (D,) or (S, D).
     (``key`` / ``num_proj_steps`` select the reference's alternating-projection branch, which it
-    disables itself — ``:150`` forces ``key=None`` because the branch returns NaN)"""
+    disables itself — ``:150`` forces ``key=None`` because the branch returns NaN)
+    ``reference_compat``: see :func:`_compat`."""
+    clip_min, method = _compat(reference_compat, clip_min, method)
     parts = _cached_parts(state, Z, D, alpha, model_type, full_set_size, clip_min, method)
     eng = parts.eng
     op = BlockOperator(lambda V: parts.apply(V.to(device=eng.device, dtype=torch.float32).contiguous()),
@@ -257,12 +269,12 @@ def inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=None, key=None,
 
 
 def sample(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None, num_proj_steps=10,
-           clip_min: Optional[float] = None, method: str = "eigh", block: int = 256):
+           clip_min: Optional[float] = None, method: str = "eigh", block: int = 256, reference_compat: bool = False):
     """``src/sample.py:148-156``: ``num_samples`` zero-mean draws A^(-1/2) eps, eps ~ N(0, I) -> (S, D).
     (theta_MAP is *not* added, as in the reference: ``:153-154``.)  eps comes from the in-kernel
     Philox generator seeded by ``key``; bit parity with JAX's threefry is not attempted."""
     fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, key=None,
-                         num_proj_steps=num_proj_steps, clip_min=clip_min, method=method)
+                         num_proj_steps=num_proj_steps, clip_min=clip_min, method=method, reference_compat=reference_compat)
     eng = fun.engine
     out = torch.empty(num_samples, eng.D, device=eng.device, dtype=torch.float32)
     for s in range(0, num_samples, block):
@@ -318,9 +330,10 @@ def sample_dense(state, Z, D, alpha, key, model_type, num_samples=1, full_set_si
 
 
 def sample_both(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None,
-                clip_min: Optional[float] = None, method: str = "eigh"):
+                clip_min: Optional[float] = None, method: str = "eigh", reference_compat: bool = False):
     """``src/sample.py:168-178``: the matrix-free and the dense sampler on the same noise."""
-    fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, clip_min=clip_min, method=method)
+    fun = inv_matsqrt_vp(state, Z, D, alpha, model_type, full_set_size=full_set_size, clip_min=clip_min, method=method,
+                         reference_compat=reference_compat)
     Eps = krylov.fill_normal(num_samples, fun.engine.D, _seed(key) * 1000003, fun.engine.device)
     samples = fun.rows(Eps)
     A = inv_matsqrt_dense(state, Z, D, alpha, model_type, full_set_size=full_set_size)

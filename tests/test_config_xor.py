@@ -117,3 +117,31 @@ def test_xor_samples_have_posterior_covariance(impl, xor):
     if impl.is_hip:
         sd_ref = torch.linalg.inv(A).diagonal().sqrt()
         assert torch.allclose(X.std(0), sd_ref, rtol=5.0 / math.sqrt(2 * S) + 1e-2)
+
+
+@pytest.mark.gpu
+def test_xor_reference_compat_matches_the_oracle_with_the_same_flags(xor):
+    """``reference_compat=True`` (= the reference's monkey-patched clip f(max(lambda, 1)) + its min(2M, d)-step
+    small-space Lanczos) at the CIFAR experiments' alpha = 0.005, where the clip is active on part of the spectrum,
+    against ``oracle/sample.py`` run with the same flags (clip 1.0, pseudo-inverse at the product's threshold).
+    PARITY UNPINNED against the reference itself; this pins the switch to the restatement.  Also
+    through ``predict_lla_scalable``'s pass-through.  Tolerance 2e-4 * max|ref| (float32 factor products)."""
+    import src.sample as hs
+    st, Z = xor["st"], xor["Z"]
+    alpha = 0.005
+    V = torch.randn(5, D, dtype=F64, generator=torch.Generator().manual_seed(12))
+    fun_o = osamp.inv_matsqrt_vp(st, Z, D, alpha, "classifier", full_set_size=N_TRAIN, clip_min=osamp.REFERENCE_CLIP_MIN,
+                                 gram_rtol=osamp.PRODUCT_GRAM_RTOL)
+    ref = torch.stack([fun_o(v) for v in V])
+    st32, Zc = st.to(device="cuda", dtype=torch.float32), Z.cuda().float()
+    fun = hs.inv_matsqrt_vp(st32, Zc, D, alpha, "classifier", full_set_size=N_TRAIN, reference_compat=True)
+    assert fun.parts.method == "lanczos" and fun.parts.clip_min == 1.0 and fun.parts.depth == 64
+    out = fun.rows(V.cuda().float()).double().cpu()
+    assert (out - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), (out - ref).abs().max().item()
+    # the clip matters at this alpha: the unclipped operator differs visibly
+    plain = hs.inv_matsqrt_vp(st32, Zc, D, alpha, "classifier", full_set_size=N_TRAIN).rows(V.cuda().float()).double().cpu()
+    assert (plain - ref).abs().max().item() > 1e-2 * ref.abs().max().item()
+    import src.lla as hl
+    S1 = hl.predict_lla_scalable(st32, Zc[:4], Zc, "classifier", alpha, key=3, full_set_size=N_TRAIN, num_samples=8,
+                                 reference_compat=True)
+    assert tuple(S1.shape) == (8, 4, 2) and bool(torch.isfinite(S1).all())
