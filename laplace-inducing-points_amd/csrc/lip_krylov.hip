@@ -8,6 +8,7 @@
 // (src/stochtrace.py:30-34).
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 #include "lip_internal.h"
 
 namespace lip {
@@ -356,12 +357,24 @@ __global__ __launch_bounds__(1024) void dot_nt_reduce_kernel(const double* __res
   }
 }
 
-static double* dot_nt_scratch() {
-  static double* bufs[64] = {nullptr};
+// Partial-tile scratch of lip_dot_nt_f64, one buffer per (device, stream): kernels of one stream are ordered, so launch
+// i's partial tiles are reduced before launch i + 1 overwrites them; a second stream or thread gets its own buffer.
+// Null when the table is full or the allocation fails — the caller then takes the float64-atomics path.
+static double* dot_nt_scratch(hipStream_t st) {
+  struct Entry { int dev; hipStream_t st; double* buf; };
+  static Entry table[16];
+  static int used = 0;
+  static std::mutex mu;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!bufs[dev] && hipMalloc((void**)&bufs[dev], sizeof(double) * DT_SCRATCH_TILES * DT_B * DT_B) != hipSuccess) bufs[dev] = nullptr;
-  return bufs[dev];
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < used; ++i)
+    if (table[i].dev == dev && table[i].st == st) return table[i].buf;
+  if (used == 16) return nullptr;
+  double* buf = nullptr;
+  if (hipMalloc((void**)&buf, sizeof(double) * DT_SCRATCH_TILES * DT_B * DT_B) != hipSuccess) return nullptr;
+  table[used++] = Entry{dev, st, buf};
+  return buf;
 }
 
 // ---- Out[i] = zscale * Z[i] + sum_j Cm[i][j] Y[j]: r combinations of the s rows of Y (s, N), streamed once per tile of
@@ -614,9 +627,9 @@ int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64
   if (ks > 65535) ks = 65535;
   const long long kper = (chunks + ks - 1) / ks * DT_KC;
   ks = (K + kper - 1) / kper;
-  // partial tiles through the per-device scratch buffer (one launch in flight per device at a time: the library is
-  // thread-compatible, not thread-safe), float64 atomics when a launch has more partial tiles than it holds
-  double* part = (ks > 1 && tiles * ks <= DT_SCRATCH_TILES) ? dot_nt_scratch() : nullptr;
+  // partial tiles through the scratch buffer of this (device, stream); float64 atomics when a launch has more partial
+  // tiles than it holds or no buffer is to be had
+  double* part = (ks > 1 && tiles * ks <= DT_SCRATCH_TILES) ? dot_nt_scratch(st) : nullptr;
   if (!part) LIP_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(double) * (size_t)m * n, st));
   hipLaunchKernelGGL(dot_nt_f64_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
                      (long long)ldb, n, (long long)K, kper, C, part);
@@ -644,7 +657,7 @@ int lip_rows_combine(const double* Cm, const float* Y, int64_t ldy, int32_t s, c
   if (Out == Y || Out == Z) { set_error("lip_rows_combine: the output must not alias an input"); return LIP_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const unsigned ny = (unsigned)((N + 1023) / 1024);
-  if (r <= 4)
+  if (r <= 4 || s > 1365)        // the coefficient tile lives in LDS (RT * s floats <= 64 KiB): 12 rows up to s = 1365, 4 rows up to 4096
     hipLaunchKernelGGL((rows_combine_kernel<4>), dim3((unsigned)((r + 3) / 4), ny), dim3(256), sizeof(float) * 4 * s, st, Cm, Y,
                        (long long)ldy, s, Z, (long long)ldz, zscale, Out, (long long)ldo, r, (long long)N);
   else

@@ -1826,7 +1826,7 @@ static int cu_count();
 // Scratch planes of the split-K launches, one buffer per (device, stream) — kernels of one stream are ordered, so the
 // shares of launch i are consumed by its finishing pass before launch i+1 overwrites them; a second stream or device
 // gets its own buffer.  Grown on demand (after draining that stream), kept for the life of the process.  Returns null
-// when the table of 16 entries is full or the allocation fails (the caller reports out-of-memory).
+// when the table of 16 entries is full or the allocation fails (the caller then launches unsplit).
 static float* ksplit_scratch(size_t floats, hipStream_t st) {
   struct Entry { int dev; hipStream_t st; float* buf; size_t cap; };
   static Entry table[16];
@@ -1905,14 +1905,17 @@ static hipError_t run_igemm(const IgemmP& p, int P, hipStream_t st) {
       if (ks > 4) ks = 4;
       const size_t plane = (size_t)P * p.R * p.N;
       if (!noks && !p.no_ksplit && !split && !par && !dbg && ks >= 2 && 2 * blocks <= cu_count() && plane * ks * sizeof(float) <= ((size_t)256 << 20)) {
-        float* scratch = ksplit_scratch(plane * ks, st);      // per (device, stream): launches of one stream are ordered
-        if (!scratch) return hipErrorOutOfMemory;
-        q.partial = scratch; q.partial_zs = (long long)plane;
-        dim3 g3((unsigned)tiles, (unsigned)P, (unsigned)ks);
-        if (bv4) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false, true, true>), g3, dim3(T::NT), 0, st, q);
-        else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false, false, true>), g3, dim3(T::NT), 0, st, q);
-        hipLaunchKernelGGL((igemm_finish_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q, (int)ks);
-        return hipGetLastError();
+        // per (device, stream): launches of one stream are ordered.  Split-K is only an optimisation: when the scratch
+        // table is full (a process rotating through many streams) or the allocation fails, the launch below runs unsplit
+        float* scratch = ksplit_scratch(plane * ks, st);
+        if (scratch) {
+          q.partial = scratch; q.partial_zs = (long long)plane;
+          dim3 g3((unsigned)tiles, (unsigned)P, (unsigned)ks);
+          if (bv4) hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false, true, true>), g3, dim3(T::NT), 0, st, q);
+          else hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, TM, TN, false, false, false, true>), g3, dim3(T::NT), 0, st, q);
+          hipLaunchKernelGGL((igemm_finish_kernel<WM, WN, TM, TN>), grid, dim3(T::NT), 0, st, q, (int)ks);
+          return hipGetLastError();
+        }
       }
     }
     if constexpr (WM == 4 && WN == 1) {
@@ -2102,7 +2105,7 @@ hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
   const bool pb_ok = !nopb && P > 1 && p.N <= 64 && (p.N & 3) == 0 && p.M >= 96 && (p.g_ps & 3) == 0 && (((uintptr_t)p.g) & 15) == 0 && (p.C & 3) == 0 && (((uintptr_t)p.a) & 15) == 0 &&
                      (long long)(P - 1) * p.g_ps + (long long)p.R * p.N < (1ll << 32);
   // measured on MI355X (CIFAR ResNet1M, P = 256): N = 32, M = 288: 3.72 -> 2.67 ms; N = 64, M = 288: 1.58 -> 1.36 ms;
-  // N = 64, M = 576 (11% padded rows with 128-row tiles): 2.61 -> 2.68 ms, so that case stays per-probe
+  // N = 64, M = 576 with 128-row tiles (11 % padded rows): 2.61 -> 2.68 ms — that case takes the 96-row tile below
   const int waste128 = (p.M + 127) / 128 * 128 - p.M;
   static const bool pb96 = getenv("LIP_NOPB96") == nullptr;     // A/B: 96-row probe-batched tile also for N = 64, M = 576
   if (pb_ok && (p.N <= 32 || 5 * waste128 >= p.M || (pb96 && p.M % 96 == 0 && p.M % 128 != 0))) {
