@@ -568,6 +568,32 @@ def main():
                                  "headline rate / total: the rest is the HBM-bound Krylov kernels and the small eigh")
         del SL
 
+    # ---- CG on (GGN + alpha I) x = b, 16 right-hand sides on the CIFAR binding (the solve inside hutchpp_inv_mvp,
+    # src/stochtrace.py:138-148, and any posterior-mean computation): plain float32 CG and CG with range(W) deflated
+    # (krylov.RangeDeflation), at the reference's CIFAR experiments' alpha = 10 and at the config's alpha = 0.005 ----
+    cg_line = None
+    if args.samples > 0 and rank == 0 and world == 1:
+        from lip_amd.sample import range_deflation
+        Bc = krylov.fill_normal(16, eng.D, 77, dev)
+        cg_line = dict(rhs=16, tol=1e-5, maxiter=200,
+                       note="iterations of the float32 recurrence (JAX's stopping rule, per right-hand side), the TRUE relative "
+                            "residual ||A x - b|| / ||b|| through the matrix-free operator afterwards, wall seconds; deflated = "
+                            "range(W) solved exactly in the sampler's eigenbasis, CG on the complement (at alpha = 0.005 the "
+                            "plain recurrence cannot converge in float32: cond(A) = 3e9)")
+        for a_cg in (10.0, 0.005):
+            Acg = lambda Vb, a=a_cg: eng.ggn_vp(Vb.contiguous(), scale, a)
+            defl = range_deflation(st_l, Zl, eng.D, a_cg, "classifier", full)
+            for tag, solver in (("plain", lambda: krylov.cg(Acg, Bc, tol=1e-5, maxiter=200, check_every=10)),
+                                ("deflated", lambda: krylov.cg_deflated(Acg, Bc, defl, tol=1e-5, maxiter=200))):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                Xc, info_c = solver()
+                torch.cuda.synchronize()
+                t_c = time.perf_counter() - t1
+                res_c = float(((Acg(Xc) - Bc).norm(dim=1) / Bc.norm(dim=1)).max().item())
+                cg_line[f"alpha={a_cg:g}_{tag}"] = dict(iterations=int(info_c["iterations"]), true_relative_residual=res_c, seconds=t_c)
+        del Bc, Xc
+
     # ---- one evaluation batch (scale_experiments/evaluate.py:98-154 times its passes): MC predictive of 256 test images ----
     eval_line = None
     if args.samples > 0 and rank == 0 and world == 1:
@@ -741,7 +767,7 @@ def main():
                                           "example_probe_products_per_s = value * examples_total is the figure that "
                                           "grows with N under weak scaling",
                                 parallelism=f"data-shard x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, eval_batch=eval_line, inducing_gradient_step=ipgrad_line, trace_estimators=trace_line, few_probes=single_line, krylov=krylov_line,
+                    roofline=roofline, cpu_baseline=cpu, posterior_samples=samples_line, factor_mode=factor_line, split_precision=split_line, resnet50=r50_line, lanczos_sampler=lanczos_line, cg_solve=cg_line, eval_batch=eval_line, inducing_gradient_step=ipgrad_line, trace_estimators=trace_line, few_probes=single_line, krylov=krylov_line,
                     checksum=float(Y.double().abs().mean().item()))
         print(json.dumps(line))
     if world > 1:

@@ -408,3 +408,50 @@ def slq_logdet_product(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: 
     _, S, Vt = torch.linalg.svd(B)
     fx = torch.log(S ** 2)
     return length2 * (Vt[:, :, 0] ** 2 * fx).sum(-1)
+
+
+class RangeDeflation:
+    """Exact treatment of an invariant subspace of a symmetric operator A: orthonormal rows ``Q`` (r, N) with
+    A q_k = ``lam[k]`` q_k.  A Krylov recurrence (Lanczos f(A) b, CG) is then run on the complement only — vectors and
+    operator outputs projected off range(Q) — and the range part of the answer is added in closed form:
+
+        f(A) b = sum_k q_k f(lam_k) <q_k, b>  +  f(A_perp) b_perp .
+
+    Why this matters in float32: the computed product A v = alpha v + beta W (W^T v) carries rounding noise of size
+    eps ||beta W W^T|| ||v||, and that noise lies (to first order) IN range(W) — W maps into it.  At the CIFAR config
+    ||beta W W^T|| = 1.5e7 and alpha = 0.005, so the noise (~1 per unit vector) swamps the bottom of the spectrum the
+    function x^(-1/2) is steepest on, and more Lanczos steps make it worse (k = 100: 26 % off, ``tests/
+    test_sampler_fullsize.py``).  Projected off range(W) the noise goes with it: what is left of the operator is
+    alpha I up to eps^2 ||A||.  The subspace comes from the sampler's orthonormalised factor (``sample.py``)."""
+
+    def __init__(self, Q: torch.Tensor, lam: torch.Tensor):
+        self.Q, self.lam = _chk(Q.contiguous()), lam.double()
+
+    def coeffs(self, V: torch.Tensor) -> torch.Tensor:
+        """<q_k, v> for the rows of V, float64 (S, r)."""
+        V = _chk(V.contiguous())
+        return dot_nt(V, self.Q) if V.shape[0] < 32 else gemm_nt(V, self.Q).double()
+
+    def project_out(self, V: torch.Tensor, C: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """V - Q^T (Q V): the rows of V projected off range(Q)."""
+        V = _chk(V.contiguous())
+        C = self.coeffs(V) if C is None else C
+        return rows_combine(-C, self.Q, Z=V, zscale=1.0)
+
+    def wrap(self, matvec: Callable) -> Callable:
+        """the operator restricted to the complement: v -> P_perp A v (for v already in the complement)"""
+        return lambda V: self.project_out(matvec(V))
+
+    def range_part(self, C: torch.Tensor, f: Callable) -> torch.Tensor:
+        """sum_k q_k f(lam_k) C[:, k] -> (S, N)"""
+        return rows_combine(C * f(self.lam)[None, :], self.Q)
+
+
+def cg_deflated(A: Callable, B: torch.Tensor, defl: RangeDeflation, **cg_kw):
+    """A^-1 B with the invariant subspace of ``defl`` solved exactly and CG run on the complement (:func:`cg`'s
+    arguments and return value; the iteration count is that of the complement solve)."""
+    B = _chk(B.contiguous())
+    C = defl.coeffs(B)
+    Xp, info = cg(defl.wrap(A), defl.project_out(B, C), **cg_kw)
+    X = axpby(defl.range_part(C, lambda lam: 1.0 / lam), Xp, None, 1.0, None, 1.0)
+    return X, info

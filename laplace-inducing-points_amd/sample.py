@@ -284,21 +284,41 @@ def sample(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=Non
     return out
 
 
+def range_deflation(state, Z, D, alpha, model_type, full_set_size=None) -> "krylov.RangeDeflation":
+    """The invariant subspace range(W) of A = alpha I + beta W W^T as the D-space Krylov routes use it: the sampler's
+    orthonormalised factor (rows q_k, A q_k = (alpha + beta lambda_k) q_k).  Needs the factor to fit in HBM."""
+    parts = _cached_parts(state, Z, D, alpha, model_type, full_set_size, None, "eigh")
+    if parts.Qm is None:
+        raise ValueError("range deflation needs the materialised factor (d * D * 4 bytes <= FACTOR_BYTES_LIMIT)")
+    lamA = (1.0 / (parts.g + 1.0 / math.sqrt(parts.alpha))) ** 2            # alpha + beta lambda_k, in Qm's row order
+    return krylov.RangeDeflation(parts.Qm, lamA)
+
+
 def sample_lanczos(state, Z, D, alpha, key, model_type, num_samples=1, full_set_size=None, num_matvecs=36,
-                   clip_min: Optional[float] = None):
+                   clip_min: Optional[float] = None, deflate: bool = False, eps: Optional[torch.Tensor] = None):
     """D-space variant: (GGN + alpha I)^(-1/2) eps by ``num_matvecs``-step Lanczos with full
     re-orthogonalisation on the matrix-free GGN-vector product (the Krylov loop of BASELINE.json's north
-    star; the reference only runs its Lanczos in the small d-space)."""
+    star; the reference only runs its Lanczos in the small d-space).
+
+    ``deflate=True``: range(W) is taken out of the recurrence and handled exactly (``krylov.RangeDeflation``) — the
+    float32 product's rounding noise lives in that subspace and is as large as alpha at the CIFAR config's alpha =
+    0.005, which is what made the plain recurrence lose accuracy with MORE steps there."""
     vp = compute_ggn_vp(state, Z, model_type, full_set_size=full_set_size)
     eng = vp.engine
     M = Z.shape[0]
     N = full_set_size or M
     scale = N / M * (math.exp(-float(state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0)
     matvec = lambda V: eng.ggn_vp(V, scale, float(alpha))
-    funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(lambda x: 1.0 / torch.sqrt(x), clip_min, floor=float(alpha)),
-                                   num_matvecs)
-    Eps = krylov.fill_normal(num_samples, eng.D, _seed(key) * 1000003, eng.device)
-    return funm(matvec, Eps)
+    f = lambda x: 1.0 / torch.sqrt(x)
+    funm = krylov.funm_lanczos_sym(krylov.dense_funm_sym_eigh(f, clip_min, floor=float(alpha)), num_matvecs)
+    Eps = krylov.fill_normal(num_samples, eng.D, _seed(key) * 1000003, eng.device) if eps is None else eps
+    if not deflate:
+        return funm(matvec, Eps)
+    defl = range_deflation(state, Z, D, alpha, model_type, full_set_size)
+    C = defl.coeffs(Eps)
+    Xp = funm(defl.wrap(matvec), defl.project_out(Eps, C))
+    fr = (lambda lam: f(torch.clamp(lam, min=clip_min))) if clip_min is not None else f
+    return krylov.axpby(defl.range_part(C, fr), Xp, None, 1.0, None, 1.0)
 
 
 def inv_matsqrt_dense(state, Z, D, alpha, model_type, full_set_size=None):
