@@ -575,23 +575,30 @@ def main():
     if args.samples > 0 and rank == 0 and world == 1:
         from lip_amd.sample import range_deflation
         Bc = krylov.fill_normal(16, eng.D, 77, dev)
-        cg_line = dict(rhs=16, tol=1e-5, maxiter=200,
+        cg_line = dict(rhs=16, tol=1e-3, maxiter=200,
                        note="iterations of the float32 recurrence (JAX's stopping rule, per right-hand side), the TRUE relative "
-                            "residual ||A x - b|| / ||b|| through the matrix-free operator afterwards, wall seconds; deflated = "
+                            "residual ||A x - b|| / ||b|| afterwards (evaluated in the invariant subspaces range(W) / complement: "
+                            "through the raw float32 product it is swamped by eps ||A|| ||x||), wall seconds; deflated = "
                             "range(W) solved exactly in the sampler's eigenbasis, CG on the complement (at alpha = 0.005 the "
-                            "plain recurrence cannot converge in float32: cond(A) = 3e9)")
+                            "plain recurrence cannot converge in float32: cond(A) = 3e9); tol 1e-3 instead of JAX's 1e-5: the noise floor of "
+                            "the deflated float32 product (tests/test_sampler_fullsize.py); a float32-stored x bounds the residual "
+                            "from below by ~eps cond (180 at alpha = 0.005), so the forward error against the closed form in the "
+                            "invariant subspaces is reported beside it")
         for a_cg in (10.0, 0.005):
             Acg = lambda Vb, a=a_cg: eng.ggn_vp(Vb.contiguous(), scale, a)
             defl = range_deflation(st_l, Zl, eng.D, a_cg, "classifier", full)
-            for tag, solver in (("plain", lambda: krylov.cg(Acg, Bc, tol=1e-5, maxiter=200, check_every=10)),
-                                ("deflated", lambda: krylov.cg_deflated(Acg, Bc, defl, tol=1e-5, maxiter=200))):
+            for tag, solver in (("plain", lambda: krylov.cg(Acg, Bc, tol=1e-3, maxiter=200, check_every=10)),
+                                ("deflated", lambda: krylov.cg_deflated(Acg, Bc, defl, tol=1e-3, maxiter=200))):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 Xc, info_c = solver()
                 torch.cuda.synchronize()
                 t_c = time.perf_counter() - t1
-                res_c = float(((Acg(Xc) - Bc).norm(dim=1) / Bc.norm(dim=1)).max().item())
-                cg_line[f"alpha={a_cg:g}_{tag}"] = dict(iterations=int(info_c["iterations"]), true_relative_residual=res_c, seconds=t_c)
+                res_c = float(defl.relative_residual(Acg, Xc, Bc).max().item())
+                Xref_c = defl.closed_form(Bc, lambda lam: 1.0 / lam, a_cg)
+                err_c = float(((Xc - Xref_c).norm(dim=1) / Xref_c.norm(dim=1)).max().item())
+                cg_line[f"alpha={a_cg:g}_{tag}"] = dict(iterations=int(info_c["iterations"]), true_relative_residual=res_c,
+                                                          forward_error_vs_closed_form=err_c, seconds=t_c)
         del Bc, Xc
 
     # ---- one evaluation batch (scale_experiments/evaluate.py:98-154 times its passes): MC predictive of 256 test images ----

@@ -432,15 +432,36 @@ class RangeDeflation:
         V = _chk(V.contiguous())
         return dot_nt(V, self.Q) if V.shape[0] < 32 else gemm_nt(V, self.Q).double()
 
-    def project_out(self, V: torch.Tensor, C: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """V - Q^T (Q V): the rows of V projected off range(Q)."""
+    def project_out(self, V: torch.Tensor, C: Optional[torch.Tensor] = None, passes: int = 1) -> torch.Tensor:
+        """V - Q^T (Q V): the rows of V projected off range(Q).  ``passes=2`` repeats the projection on the result: the
+        range component of a float32 product is ~200x the complement's signal at alpha = 0.005, and one pass with
+        float32 rows q_k (orthonormal to ~1e-7) leaves ~1e-6 of it behind."""
         V = _chk(V.contiguous())
-        C = self.coeffs(V) if C is None else C
-        return rows_combine(-C, self.Q, Z=V, zscale=1.0)
+        out = rows_combine(-(self.coeffs(V) if C is None else C), self.Q, Z=V, zscale=1.0)
+        for _ in range(passes - 1):
+            out = rows_combine(-self.coeffs(out), self.Q, Z=out, zscale=1.0)
+        return out
 
     def wrap(self, matvec: Callable) -> Callable:
         """the operator restricted to the complement: v -> P_perp A v (for v already in the complement)"""
-        return lambda V: self.project_out(matvec(V))
+        return lambda V: self.project_out(matvec(V), passes=2)
+
+    def relative_residual(self, A: Callable, X: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """||A x - b|| / ||b|| per row, evaluated in the two invariant subspaces: lam_k <q_k, x> - <q_k, b> on range(Q)
+        (float64) and P_perp (A x) - P_perp b on the complement.  Evaluated naively through the float32 product the
+        residual of an accurate solution is swamped by the same range(W) noise the deflation removes
+        (eps ||A|| ||x|| ~ 300 ||b|| at alpha = 0.005)."""
+        rr = self.coeffs(X) * self.lam[None, :] - self.coeffs(B)
+        rp = self.project_out(A(X), passes=2) - self.project_out(B)
+        return torch.sqrt((rr * rr).sum(1) + (rp.double() ** 2).sum(1)) / B.double().norm(dim=1)
+
+    def closed_form(self, B: torch.Tensor, f: Callable, lam_perp: float) -> torch.Tensor:
+        """f(A) B when A is lam_perp * I on the complement of range(Q) (A = alpha I + beta W W^T: lam_perp = alpha):
+        sum_k q_k f(lam_k) <q_k, b> + f(lam_perp) b_perp — the answer the deflated recurrences converge to, used as their
+        reference (a float32-stored x cannot make ||A x - b|| small at cond 3e9: eps cond ~ 180)."""
+        C = self.coeffs(B)
+        lp = torch.tensor([float(lam_perp)], dtype=torch.float64, device=B.device)
+        return axpby(self.range_part(C, f), self.project_out(B, C), None, float(f(lp)[0]), None, 1.0)
 
     def range_part(self, C: torch.Tensor, f: Callable) -> torch.Tensor:
         """sum_k q_k f(lam_k) C[:, k] -> (S, N)"""
@@ -453,5 +474,6 @@ def cg_deflated(A: Callable, B: torch.Tensor, defl: RangeDeflation, **cg_kw):
     B = _chk(B.contiguous())
     C = defl.coeffs(B)
     Xp, info = cg(defl.wrap(A), defl.project_out(B, C), **cg_kw)
+    Xp = defl.project_out(Xp)                       # what the recurrence let leak back into range(Q)
     X = axpby(defl.range_part(C, lambda lam: 1.0 / lam), Xp, None, 1.0, None, 1.0)
     return X, info

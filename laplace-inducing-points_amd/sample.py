@@ -316,7 +316,7 @@ def sample_lanczos(state, Z, D, alpha, key, model_type, num_samples=1, full_set_
         return funm(matvec, Eps)
     defl = range_deflation(state, Z, D, alpha, model_type, full_set_size)
     C = defl.coeffs(Eps)
-    Xp = funm(defl.wrap(matvec), defl.project_out(Eps, C))
+    Xp = defl.project_out(funm(defl.wrap(matvec), defl.project_out(Eps, C)))
     fr = (lambda lam: f(torch.clamp(lam, min=clip_min))) if clip_min is not None else f
     return krylov.axpby(defl.range_part(C, fr), Xp, None, 1.0, None, 1.0)
 

@@ -147,17 +147,23 @@ def test_deflated_lanczos_sampler_at_the_config_alpha(setup, k):
 
 
 def test_deflated_cg_solves_the_config_system(setup):
-    """(GGN + alpha I) x = b at alpha = 0.005 (cond 3e9): plain float32 CG stagnates far from the solution; with
-    range(W) deflated the complement solve converges in a couple of iterations and the true residual, measured through
-    the matrix-free operator relative to ||b||, is at float32 level."""
+    """(GGN + alpha I) x = b at alpha = 0.005 (cond 3e9): plain float32 CG is nowhere near the solution after 50 steps;
+    with range(W) deflated the complement solve converges in a couple of iterations.  Reference: the closed form in the
+    invariant subspaces (``RangeDeflation.closed_form``); asserted is the FORWARD error — a float32-stored x cannot
+    make the residual small at this conditioning (eps * cond = 180; the residual evaluated subspace-wise is printed).
+    Stopping tolerance 1e-3: the floor of the deflated float32 product (the deflated Lanczos draws show the same
+    8e-4 .. 1.6e-3), below which a float32 CG only accumulates rounding (tol 1e-6: 50 iterations, error O(1))."""
     from lip_amd import krylov
     from lip_amd.sample import range_deflation
     s = setup
     B = s["V"][:8].contiguous()
     defl = range_deflation(s["st"], s["Z"], s["eng"].D, ALPHA, "classifier", FULL)
-    X, info = krylov.cg_deflated(s["A"], B, defl, tol=1e-6, maxiter=50)
-    res = ((s["A"](X) - B).norm(dim=1) / B.norm(dim=1)).max().item()
-    Xp, infop = krylov.cg(s["A"], B, tol=1e-6, maxiter=50)
-    resp = ((s["A"](Xp) - B).norm(dim=1) / B.norm(dim=1)).max().item()
-    print(f"SAMPLER_FULLSIZE cg alpha={ALPHA}: deflated {info['iterations']} iterations residual {res:.3e}; plain 50 iterations residual {resp:.3e}")
-    assert info["iterations"] <= 10 and res <= 1e-3
+    Xref = defl.closed_form(B, lambda lam: 1.0 / lam, ALPHA)
+    X, info = krylov.cg_deflated(s["A"], B, defl, tol=1e-3, maxiter=50)
+    err = ((X - Xref).norm(dim=1) / Xref.norm(dim=1)).max().item()
+    res = defl.relative_residual(s["A"], X, B).max().item()
+    Xp, infop = krylov.cg(s["A"], B, tol=1e-3, maxiter=50)
+    errp = ((Xp - Xref).norm(dim=1) / Xref.norm(dim=1)).max().item()
+    print(f"SAMPLER_FULLSIZE cg alpha={ALPHA}: deflated {info['iterations']} iterations forward error {err:.3e} (subspace residual "
+          f"{res:.3e}); plain {infop['iterations']} iterations forward error {errp:.3e}")
+    assert info["iterations"] <= 8 and err <= 2e-2 and errp > 0.5          # measured 5 iterations, 8e-3; plain 0.74
