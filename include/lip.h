@@ -202,6 +202,12 @@ int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64
  * run to run).  W^T applied to a block of draws on a materialised factor (src/sample.py:130-139).             */
 int lip_gemm_nt(const float* A, int64_t lda, int32_t m, const float* B, int64_t ldb, int32_t n, int64_t K, float* C,
                 void* stream);
+/* Out (m, N) = T (m, k) B (k, N) + beta V (m, N): float32 MFMA, short reduction k (rows of a materialised factor), very
+ * long N (= D); row strides ldt >= k, ldb / ldv / ldo >= N.  V may be NULL (no addend) or Out itself (in place); Out must
+ * not alias T or B.  The second pass of a block of posterior draws, x = alpha^(-1/2) eps + (coefficients) Qm
+ * (src/sample.py:139-143 in the Gram's eigenbasis), and the second product of the factor-mode GGN-vp.        */
+int lip_gemm_nn_axpy(const float* T, int64_t ldt, int32_t m, int32_t k, const float* B, int64_t ldb, int64_t N, const float* V,
+                     int64_t ldv, float beta, float* Out, int64_t ldo, void* stream);
 /* Out[i] = zscale * Z[i] + sum_j Cm[i][j] Y[j],  i < r: r combinations of the s rows of Y (s, N) in one streaming pass
  * per 12 output rows; Cm (r, s) float64 row-major on the device, Z (r, N) optional (NULL: no addend).  Replaces
  * jnp.linalg.qr's Q of src/stochtrace.py:128 (as L^-1 Y after a Gram factorisation) and the deflation

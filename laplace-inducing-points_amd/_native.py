@@ -81,6 +81,8 @@ SIGNATURES = {
     "lip_cg_direction": (C.c_int, [_V, _V, _V, _V, _V, C.c_int32, C.c_int64, _V]),
     "lip_dot_nt_f64": (C.c_int, [_V, C.c_int64, C.c_int32, _V, C.c_int64, C.c_int32, C.c_int64, _V, _V]),
     "lip_gemm_nt": (C.c_int, [_V, C.c_int64, C.c_int32, _V, C.c_int64, C.c_int32, C.c_int64, _V, _V]),
+    "lip_gemm_nn_axpy": (C.c_int, [_V, C.c_int64, C.c_int32, C.c_int32, _V, C.c_int64, C.c_int64, _V, C.c_int64, C.c_float, _V,
+                                   C.c_int64, _V]),
     "lip_rows_combine": (C.c_int, [_V, _V, C.c_int64, C.c_int32, _V, C.c_int64, C.c_float, _V, C.c_int64, C.c_int32,
                                    C.c_int64, _V]),
     "lip_fill_rademacher": (C.c_int, [_V, C.c_int32, C.c_int64, C.c_uint64, _V]),

@@ -383,7 +383,7 @@ int ready(const lip_engine* e, const char* who) {
 
 extern "C" {
 
-int lip_abi_version(void) { return 6; }
+int lip_abi_version(void) { return 7; }
 const char* lip_last_error(void) { return g_err; }
 int lip_sizeof_op(void) { return (int)sizeof(lip_op_t); }
 int lip_set_precision(int32_t mode) { if (mode != 0 && mode != 1) { set_error("lip_set_precision: mode must be 0 (f32) or 1 (bf16x3)"); return LIP_ERR_ARG; } set_precision_mode(mode); return LIP_OK; }

@@ -146,6 +146,8 @@ hipError_t launch_softmax(const float* logits, float* prob, float* sqrtp, int n,
 hipError_t launch_head(const HeadP& p, int P, hipStream_t st);
 hipError_t launch_gemm_nt(const float* A, long long lda, int m, const float* B, long long ldb, int n, long long K, float* C,
                           hipStream_t st);
+hipError_t launch_gemm_nn_axpy(const float* T, long long ldt, int m, int k, const float* B, long long ldb, long long N,
+                               const float* V, long long ldv, float beta, float* Out, long long ldo, hipStream_t st);
 hipError_t launch_scale_copy(float* y, const float* x, float a, long long count, hipStream_t st);
 // y[p][off + i] = a * x[p][off + i] (x null: 0) for i < len, p < P, row stride ld: the parameters a fused weight gradient
 // does NOT write (biases, BN parameters, layers on the accumulate path)

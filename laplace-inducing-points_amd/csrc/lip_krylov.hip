@@ -648,6 +648,22 @@ int lip_gemm_nt(const float* A, int64_t lda, int32_t m, const float* B, int64_t 
   return LIP_OK;
 }
 
+int lip_gemm_nn_axpy(const float* T, int64_t ldt, int32_t m, int32_t k, const float* B, int64_t ldb, int64_t N, const float* V,
+                     int64_t ldv, float beta, float* Out, int64_t ldo, void* stream) {
+  if (!T || !B || !Out || m <= 0 || k <= 0 || N <= 0 || ldt < k || ldb < N || ldo < N || (V && ldv < N)) {
+    set_error("lip_gemm_nn_axpy: bad argument");
+    return LIP_ERR_ARG;
+  }
+  if (Out == B || Out == T) { set_error("lip_gemm_nn_axpy: the output must not alias T or B (it may alias V)"); return LIP_ERR_ARG; }
+  if (V && V != Out && V < Out + (size_t)(m - 1) * ldo + N && Out < V + (size_t)(m - 1) * ldv + N) {
+    set_error("lip_gemm_nn_axpy: V overlaps the output without being it");
+    return LIP_ERR_ARG;
+  }
+  LIP_CHECK_HIP(launch_gemm_nn_axpy(T, (long long)ldt, m, k, B, (long long)ldb, (long long)N, V, (long long)ldv, beta, Out,
+                                    (long long)ldo, (hipStream_t)stream));
+  return LIP_OK;
+}
+
 int lip_rows_combine(const double* Cm, const float* Y, int64_t ldy, int32_t s, const float* Z, int64_t ldz, float zscale,
                      float* Out, int64_t ldo, int32_t r, int64_t N, void* stream) {
   if (!Cm || !Y || !Out || s <= 0 || r <= 0 || N <= 0 || ldy < N || ldo < N || (Z && ldz < N) || s > 4096) {

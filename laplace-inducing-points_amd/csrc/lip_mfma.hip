@@ -1777,6 +1777,145 @@ hipError_t launch_gemm_nt(const float* A, long long lda, int m, const float* B, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Out (m, N) = T (m, k) B (k, N) + beta V (m, N) for a SHORT reduction k (the d <= ~1000 rows of a materialised factor) and
+// a very long N (= D ~ 1e6): the second pass of every posterior draw,  x = alpha^(-1/2) eps + (coefficients) Qm
+// (src/sample.py:139-143 collapsed, see sample.py), and the second product of the factor-mode GGN-vp.  T is tiny and
+// K-contiguous (transposing k-major LDS store, as the implicit-GEMM A operand), B rows run along N (k-major as stored:
+// float4 rows), 128 x 128 tile, f32 MFMA, the same pipelined K loop; the addend rides in the epilogue and may alias
+// Out (every element is read before it is written, by the thread that writes it).  Replaces torch.addmm (hipBLASLt).
+// ------------------------------------------------------------------------------------------
+struct GemmNnP {
+  const float* t; long long ldt; int m, k;
+  const float* b; long long ldb; long long N;
+  const float* v; long long ldv; float beta;
+  float* out; long long ldo;
+};
+
+__global__ __launch_bounds__(256) void gemm_nn_axpy_kernel(const GemmNnP prm) {
+  using T = Tile<2, 2, 2, 2>;
+  constexpr int NT = T::NT, BM = T::BM, BN = T::BN, AE = T::AE, AQ = T::AQ;      // 256 threads, 128 x 128
+  constexpr int BE = BN * BK / NT, BQ = BE / 4;                                   // 8 floats = 2 float4 of B per thread and K-tile
+  constexpr int LDA = BM + 2, LDB = BN;
+  constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+  __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // block -> (column tile, row tile), row tile fastest, and every XCD a contiguous run of blocks: the row tiles of a
+  // column tile read the same 128-column slab of B and should find it in one L2
+  const int tiles_m = (prm.m + BM - 1) / BM;
+  long long bid = blockIdx.x;
+  {
+    const long long g8 = (long long)gridDim.x & ~7ll;
+    if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+  }
+  const int m0 = (int)(bid % tiles_m) * BM;
+  const long long n0 = (bid / tiles_m) * BN;
+  const int ktiles = (prm.k + BK - 1) / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  // A: quad q = tid + j * NT -> (row = q >> 2, k-quad kq4 = 4 * (tid & 3))
+  const int kq4 = (tid & 3) * 4;
+  const float* arow[AQ];
+  bool aok[AQ];
+#pragma unroll
+  for (int j = 0; j < AQ; ++j) {
+    const int row = (tid + j * NT) >> 2;
+    aok[j] = m0 + row < prm.m;
+    arow[j] = prm.t + (long long)(aok[j] ? m0 + row : 0) * prm.ldt + kq4;
+  }
+  // B: float4 e = tid + j * NT -> (k = e / 32, column quad nq = e % 32)
+  int bk[BQ];
+  long long bcol[BQ];
+  bool bok4[BQ];
+#pragma unroll
+  for (int j = 0; j < BQ; ++j) {
+    const int e = tid + j * NT;
+    bk[j] = e / (BN / 4);
+    bcol[j] = n0 + 4 * (e % (BN / 4));
+    bok4[j] = bcol[j] + 3 < prm.N;
+  }
+  int k0 = 0;
+  auto load_tile = [&](float (&areg)[AE], float (&breg)[BE]) {
+#pragma unroll
+    for (int j = 0; j < AQ; ++j) {
+      const int k = k0 + kq4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) areg[4 * j + t] = (aok[j] && k + t < prm.k) ? arow[j][k0 + t] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < BQ; ++j) {
+      const int k = k0 + bk[j];
+      const float* src = prm.b + (long long)(k < prm.k ? k : 0) * prm.ldb + bcol[j];
+      if (k < prm.k && bok4[j]) {
+        const float4u v = *reinterpret_cast<const float4u*>(src);
+        breg[4 * j + 0] = v[0]; breg[4 * j + 1] = v[1]; breg[4 * j + 2] = v[2]; breg[4 * j + 3] = v[3];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) breg[4 * j + t] = (k < prm.k && bcol[j] + t < prm.N) ? src[t] : 0.f;
+      }
+    }
+  };
+  auto store_tile = [&](const float (&areg)[AE], const float (&breg)[BE], float* Asb, float* Bsb) {
+#pragma unroll
+    for (int j = 0; j < AQ; ++j) {
+      const int row = (tid + j * NT) >> 2;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Asb[(kq4 + t) * LDA + row] = areg[4 * j + t];
+    }
+#pragma unroll
+    for (int j = 0; j < BQ; ++j) {
+      const int e = tid + j * NT;
+      *reinterpret_cast<float4*>(&Bsb[(e / (BN / 4)) * LDB + 4 * (e % (BN / 4))]) =
+          make_float4(breg[4 * j + 0], breg[4 * j + 1], breg[4 * j + 2], breg[4 * j + 3]);
+    }
+  };
+  auto advance = [&]() { k0 += BK; };
+  pipelined_k_loop<AE, BE, ASZ, BSZ>(ktiles, As, Bs, load_tile, store_tile, advance,
+                                     [&](const float* Asb, const float* Bsb) { mfma_sweep<2, 2, 2, 2, LDA, LDB>(Asb, Bsb, acc, wm, wn, lane); });
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float beta = prm.v ? prm.beta : 0.f;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const long long col = n0 + (wn * 2 + tn) * 32 + l31;
+    const bool cv = col < prm.N;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int rb = m0 + (wm * 2 + tm) * 32 + 4 * lh;
+      float add[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {                       // all loads of the phase first, then its stores
+        const int r = rb + (q & 3) + 8 * (q >> 2);
+        const bool ok = cv && r < prm.m && prm.v;
+        add[q] = ok ? prm.v[(long long)r * prm.ldv + col] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int r = rb + (q & 3) + 8 * (q >> 2);
+        if (cv && r < prm.m) prm.out[(long long)r * prm.ldo + col] = acc[tm][tn][q] + beta * add[q];
+      }
+    }
+  }
+}
+
+hipError_t launch_gemm_nn_axpy(const float* T, long long ldt, int m, int k, const float* B, long long ldb, long long N,
+                               const float* V, long long ldv, float beta, float* Out, long long ldo, hipStream_t st) {
+  GemmNnP p;
+  p.t = T; p.ldt = ldt; p.m = m; p.k = k; p.b = B; p.ldb = ldb; p.N = N; p.v = V; p.ldv = ldv; p.beta = beta; p.out = Out; p.ldo = ldo;
+  const long long blocks = (long long)((m + 127) / 128) * ((N + 127) / 128);
+  hipLaunchKernelGGL(gemm_nn_axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers: pick the tile shape from the problem shape
 // ------------------------------------------------------------------------------------------
 // 256 bytes of device zeros (per device): the source of masked gather rows in the fast kernels.

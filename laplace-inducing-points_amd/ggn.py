@@ -211,7 +211,7 @@ def compute_ggn_vp(state, Z, model_type, full_set_size=None, mode: str = "matfre
         from . import krylov
         Vb = Vb.contiguous()
         U = krylov.gemm_nt(Vb, Wm) if Vb.shape[0] >= 32 else Vb @ Wm.T      # both operands run along D: lip_gemm_nt
-        return U @ Wm                                                        # (P, d)(d, D): library GEMM
+        return krylov.gemm_nn_axpy(U.contiguous(), Wm)                       # (P, d)(d, D): lip_gemm_nn_axpy
 
     op = BlockOperator(apply, (eng.D,), (eng.D,), eng, "ggn_vp[factor]")
     op.factor = Wm

@@ -93,6 +93,27 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return C
 
 
+def gemm_nn_axpy(T: torch.Tensor, B: torch.Tensor, V: Optional[torch.Tensor] = None, beta: float = 1.0,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T B + beta V for T (m, k) float32, B (k, N) float32 rows, V (m, N) or None; ``out`` may be V (in place).  The
+    hand-written NN-layout MFMA kernel with the addend in its epilogue (``lip_gemm_nn_axpy``)."""
+    lib = nv.load()
+    T, ldt = _rows_f32(T)
+    B, ldb = _rows_f32(B)
+    if T.shape[1] != B.shape[0]:
+        raise ValueError(f"gemm_nn_axpy: inner dimensions differ ({T.shape[1]} vs {B.shape[0]})")
+    m, N = T.shape[0], B.shape[1]
+    O = torch.empty(m, N, device=B.device, dtype=torch.float32) if out is None else out
+    O, ldo = _rows_f32(O)
+    vp, ldv = 0, 0
+    if V is not None:
+        V, ldv = _rows_f32(V)
+        vp = V.data_ptr()
+    nv.check(lib.lip_gemm_nn_axpy(T.data_ptr(), ldt, m, T.shape[1], B.data_ptr(), ldb, N, vp, ldv, float(beta), O.data_ptr(), ldo,
+                                  nv.stream_ptr()), "lip_gemm_nn_axpy")
+    return O
+
+
 def rows_combine(Cm: torch.Tensor, Y: torch.Tensor, Z: Optional[torch.Tensor] = None, zscale: float = 0.0,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i] = zscale * Z[i] + sum_j Cm[i, j] Y[j]: r combinations of the s rows of Y in one streaming pass

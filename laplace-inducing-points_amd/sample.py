@@ -198,7 +198,7 @@ class _SamplerParts:
         T, B = self._correction(V)
         a = 1.0 / math.sqrt(self.alpha)
         if B is not None:
-            return torch.addmm(V, T, B, beta=a, alpha=1.0)                                 # W x + alpha^(-1/2) v in one pass
+            return krylov.gemm_nn_axpy(T, B, V, a)                                         # W x + alpha^(-1/2) v in one pass (lip_gemm_nn_axpy)
         out = self.Wfun.rows(T.reshape((V.shape[0],) + self.inner))                        # one W sweep, matrix-free
         return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
 
@@ -211,7 +211,7 @@ class _SamplerParts:
         if B is None:
             V.copy_(self.apply(V))
             return V
-        return torch.addmm(V, T, B, beta=1.0 / math.sqrt(self.alpha), alpha=1.0, out=V)
+        return krylov.gemm_nn_axpy(T, B, V, 1.0 / math.sqrt(self.alpha), out=V)
 
 
 _PARTS_CACHE = {}

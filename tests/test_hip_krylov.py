@@ -158,3 +158,30 @@ def test_gemm_nt(m, n, K):
         Cv = krylov.gemm_nt(Av, B)
         refv = Av.double() @ B.double().T
         assert ((Cv.double() - refv).abs() / (Av.double().norm(dim=1)[:, None] * B.double().norm(dim=1)[None, :])).max().item() <= 2e-6
+
+
+def test_gemm_nn_axpy_matches_float64():
+    """lip_gemm_nn_axpy: Out = T B + beta V (second pass of a block of posterior draws; factor-mode second product) for
+    ragged m / k / N, with and without the addend, out of place and in place; 2e-6 * max|ref| (f32 MFMA = fmaf chain)."""
+    from lip_amd import krylov
+    g = torch.Generator().manual_seed(3)
+    for (m, k, N) in ((256, 450, 100003), (7, 33, 1300), (130, 16, 257), (1, 500, 4099)):
+        T = torch.randn(m, k, generator=g).cuda()
+        B = torch.randn(k, N, generator=g).cuda()
+        V = torch.randn(m, N, generator=g).cuda()
+        ref = T.double() @ B.double() + 0.37 * V.double()
+        out = krylov.gemm_nn_axpy(T, B, V, 0.37)
+        assert (out.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), (m, k, N)
+        out0 = krylov.gemm_nn_axpy(T, B)
+        ref0 = T.double() @ B.double()
+        assert (out0.double() - ref0).abs().max().item() <= 2e-6 * ref0.abs().max().item()
+        Vc = V.clone()
+        krylov.gemm_nn_axpy(T, B, Vc, 0.37, out=Vc)             # in place: the addend is the output
+        assert torch.equal(Vc, out)
+    # strided rows (a slice of a wider matrix) for B and V
+    Bw = torch.randn(40, 3000, generator=g).cuda()
+    Tw = torch.randn(9, 40, generator=g).cuda()
+    Vw = torch.randn(9, 3000, generator=g).cuda()
+    o = krylov.gemm_nn_axpy(Tw, Bw[:, 100:1100], Vw[:, 5:1005], 2.0)
+    r = Tw.double() @ Bw[:, 100:1100].double() + 2.0 * Vw[:, 5:1005].double()
+    assert (o.double() - r).abs().max().item() <= 2e-6 * r.abs().max().item()
