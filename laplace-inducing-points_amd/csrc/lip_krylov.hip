@@ -650,8 +650,8 @@ int lip_gemm_nt(const float* A, int64_t lda, int32_t m, const float* B, int64_t 
 
 int lip_gemm_nn_axpy(const float* T, int64_t ldt, int32_t m, int32_t k, const float* B, int64_t ldb, int64_t N, const float* V,
                      int64_t ldv, float beta, float* Out, int64_t ldo, void* stream) {
-  if (!T || !B || !Out || m <= 0 || k <= 0 || N <= 0 || ldt < k || ldb < N || ldo < N || (V && ldv < N)) {
-    set_error("lip_gemm_nn_axpy: bad argument");
+  if (!T || !B || !Out || m <= 0 || k < 4 || N < 4 || ldt < k || ldb < N || ldo < N || (V && ldv < N)) {
+    set_error("lip_gemm_nn_axpy: bad argument (k and N must be at least 4)");
     return LIP_ERR_ARG;
   }
   if (Out == B || Out == T) { set_error("lip_gemm_nn_axpy: the output must not alias T or B (it may alias V)"); return LIP_ERR_ARG; }

@@ -103,6 +103,9 @@ def gemm_nn_axpy(T: torch.Tensor, B: torch.Tensor, V: Optional[torch.Tensor] = N
     if T.shape[1] != B.shape[0]:
         raise ValueError(f"gemm_nn_axpy: inner dimensions differ ({T.shape[1]} vs {B.shape[0]})")
     m, N = T.shape[0], B.shape[1]
+    if T.shape[1] < 4 or N < 4:                     # below the kernel's vector width: a handful of rows / columns
+        res = T @ B if V is None else torch.addmm(V, T, B, beta=float(beta))
+        return res if out is None else out.copy_(res)
     O = torch.empty(m, N, device=B.device, dtype=torch.float32) if out is None else out
     O, ldo = _rows_f32(O)
     vp, ldv = 0, 0
