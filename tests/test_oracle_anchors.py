@@ -276,3 +276,146 @@ def test_sqrt_factor_forms(impl):
     assert (L @ torch.sqrt(p)).abs().max().item() <= tol
     assert (LT - L.T).abs().max().item() <= tol
     assert (L - (torch.diag(torch.sqrt(p)) - torch.outer(p, torch.sqrt(p)))).abs().max().item() <= tol
+
+
+# ------------------------------------------------------------------------------------------------ (d) GELU MLP
+def test_gelu_mlp_regressor_against_explicit_jacobians(impl):
+    """``SimpleRegressor`` (``src/toymodels.py:4-24``: Dense -> GELU -> Dense -> GELU -> Dense(1), scalar logvar outside
+    theta) written by hand — flax.linen.gelu's default tanh form, bias-before-kernel sorted-key layout — and
+    differentiated by ``jacrev``: GGN v = exp(-logvar) (N / M) sum_i J_i^T J_i v  (``src/ggn.py:111-113``)."""
+    from lip_amd.toymodels import SimpleRegressor
+    h, n, N = 5, 4, 12
+    shapes = [(("Dense_0", "bias"), (h,)), (("Dense_0", "kernel"), (1, h)), (("Dense_1", "bias"), (h,)),
+              (("Dense_1", "kernel"), (h, h)), (("Dense_2", "bias"), (1,)), (("Dense_2", "kernel"), (h, 1))]
+    D = sum(math.prod(s) for _, s in shapes)
+    theta = 0.8 * _randn(41, D)
+    logvar = torch.tensor(-0.3, dtype=F64)
+
+    def gelu(x):                                                          # 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+        return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+    def forward(th, x):                                                   # x (1,) -> (1,)
+        p = _unflat(th, shapes)
+        a = gelu(x @ p["Dense_0"]["kernel"] + p["Dense_0"]["bias"])
+        a = gelu(a @ p["Dense_1"]["kernel"] + p["Dense_1"]["bias"])
+        return a @ p["Dense_2"]["kernel"] + p["Dense_2"]["bias"]
+
+    def apply_fn(variables, x, return_logvar=False, **_):                 # hand-written; not NetSpec.forward
+        th = torch.cat([_get(variables["params"], pth).reshape(-1) for pth, _ in shapes])
+        return forward(th, x) if x.dim() == 1 else torch.stack([forward(th, xi) for xi in x])
+
+    net = SimpleRegressor(h, 2)
+    params = {"params": _unflat(theta, shapes), "logvar": {"logvar": logvar}}
+    st = TrainState(params=params, apply_fn=apply_fn, batch_stats={}, net=net)
+    flat, _ = flatten_nn_params(st.params)
+    assert torch.equal(flat, theta)                                       # logvar is not part of theta
+    Z = _randn(42, n, 1)
+    assert torch.allclose(net.forward(st.params, st.batch_stats, Z), torch.stack([forward(theta, z) for z in Z]),
+                          rtol=1e-12, atol=1e-13)
+    V = _randn(43, 3, D)
+    ref = torch.zeros_like(V)
+    for z in Z:
+        J = jacrev(lambda th: forward(th, z))(theta)                      # (1, D)
+        ref += V @ J.T @ J
+    ref = ref * torch.exp(-logvar) * (N / n)
+    vp = impl.ggn.compute_ggn_vp(impl.state(st), impl.tensor(Z), "regressor", full_set_size=N)
+    Y = impl.rows(vp, impl.tensor(V))
+    assert (cpu64(Y) - ref).abs().max().item() <= impl.tol(1e-11, 3e-5) * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ (e) max pool + bottleneck
+def _conv_pad(x, w, stride, pad):
+    """convolution with symmetric zero padding ``pad`` (torch convention), x (H, W, Cin), w HWIO — from the definition"""
+    H, Wd, _ = x.shape
+    kh, kw, _, co = w.shape
+    oh, ow = (H + 2 * pad - kh) // stride + 1, (Wd + 2 * pad - kw) // stride + 1
+    xp = torch.nn.functional.pad(x, (0, 0, pad, pad, pad, pad))
+    out = 0.0
+    for i in range(kh):
+        for j in range(kw):
+            out = out + xp[i:i + (oh - 1) * stride + 1:stride, j:j + (ow - 1) * stride + 1:stride] @ w[i, j]
+    return out
+
+
+def _maxpool_pad(x, k, stride, pad):
+    """k x k / stride max pool, padding ``pad`` with -inf (a padded position never wins)"""
+    H, Wd, C = x.shape
+    oh, ow = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
+    xp = torch.nn.functional.pad(x, (0, 0, pad, pad, pad, pad), value=float("-inf"))
+    out = torch.full((oh, ow, C), float("-inf"), dtype=x.dtype)
+    for i in range(k):
+        for j in range(k):
+            out = torch.maximum(out, xp[i:i + (oh - 1) * stride + 1:stride, j:j + (ow - 1) * stride + 1:stride])
+    return out
+
+
+def test_maxpool_bottleneck_net_against_explicit_jacobians(impl):
+    """The ResNet-50 pattern of BASELINE configs[4] at test size (``scalemodels.ResNet50(K, (20, 20, 3), stem 8, widths
+    (4, 8), blocks (1, 1))``): 7x7/2 stem + BN + ReLU, 3x3/2 max pool with padding, a bottleneck with projection
+    shortcut, a stride-2 bottleneck, mean pool, Dense — written by hand (symmetric padding, -inf pool padding,
+    sorted-key flat layout) with per-example ``jacrev`` and the explicit diag(p) - p p^T."""
+    from lip_amd.scalemodels import ResNet50
+    K, hw, stem, n = 5, 20, 8, 2
+    def bott(cin, planes, proj):
+        names = [("BatchNorm_0", "bias", (planes,)), ("BatchNorm_0", "scale", (planes,)),
+                 ("BatchNorm_1", "bias", (planes,)), ("BatchNorm_1", "scale", (planes,)),
+                 ("BatchNorm_2", "bias", (4 * planes,)), ("BatchNorm_2", "scale", (4 * planes,))]
+        if proj:
+            names += [("BatchNorm_3", "bias", (4 * planes,)), ("BatchNorm_3", "scale", (4 * planes,))]
+        names += [("Conv_0", "kernel", (1, 1, cin, planes)), ("Conv_1", "kernel", (3, 3, planes, planes)),
+                  ("Conv_2", "kernel", (1, 1, planes, 4 * planes))]
+        if proj:
+            names += [("Conv_3", "kernel", (1, 1, cin, 4 * planes))]
+        return names
+    layout = [(("BatchNorm_0", "bias"), (stem,)), (("BatchNorm_0", "scale"), (stem,))]
+    layout += [(("Bottleneck_0",) + nm[:2], nm[2]) for nm in bott(stem, 4, True)]
+    layout += [(("Bottleneck_1",) + nm[:2], nm[2]) for nm in bott(16, 8, True)]
+    layout += [(("Conv_0", "kernel"), (7, 7, 3, stem)), (("Dense_0", "bias"), (K,)), (("Dense_0", "kernel"), (32, K))]
+    D = sum(math.prod(s) for _, s in layout)
+    theta = _randn(51, D)
+    tree = _unflat(theta, layout)
+    for path, shape in layout:
+        t = _get(tree, path[:-1])
+        if path[-1] == "kernel":
+            t[path[-1]] = t[path[-1]] / math.sqrt(math.prod(shape[:-1]))
+        elif path[-1] == "scale":
+            t[path[-1]] = 1.0 + 0.2 * t[path[-1]]
+        else:
+            t[path[-1]] = 0.1 * t[path[-1]]
+    theta = torch.cat([_get(tree, p).reshape(-1) for p, _ in layout])
+    stats, g = {}, torch.Generator().manual_seed(52)
+    for path, shape in layout:
+        if path[-2].startswith("BatchNorm") and path[-1] == "bias":
+            t = stats
+            for k in path[:-2]:
+                t = t.setdefault(k, {})
+            t[path[-2]] = {"mean": 0.1 * torch.randn(shape, generator=g, dtype=F64), "var": 0.5 + torch.rand(shape, generator=g, dtype=F64)}
+
+    def forward(th, x):
+        p = _unflat(th, layout)
+        bn = lambda z, pp, ss: _bn_eval(z, pp["scale"], pp["bias"], ss["mean"], ss["var"])
+        h = torch.relu(bn(_conv_pad(x, p["Conv_0"]["kernel"], 2, 3), p["BatchNorm_0"], stats["BatchNorm_0"]))
+        h = _maxpool_pad(h, 3, 2, 1)
+        for name, stride in (("Bottleneck_0", 1), ("Bottleneck_1", 2)):
+            b, s = p[name], stats[name]
+            r = bn(_conv_pad(h, b["Conv_3"]["kernel"], stride, 0), b["BatchNorm_3"], s["BatchNorm_3"])
+            y = torch.relu(bn(_conv_pad(h, b["Conv_0"]["kernel"], 1, 0), b["BatchNorm_0"], s["BatchNorm_0"]))
+            y = torch.relu(bn(_conv_pad(y, b["Conv_1"]["kernel"], stride, 1), b["BatchNorm_1"], s["BatchNorm_1"]))
+            h = torch.relu(bn(_conv_pad(y, b["Conv_2"]["kernel"], 1, 0), b["BatchNorm_2"], s["BatchNorm_2"]) + r)
+        return h.mean(dim=(0, 1)) @ p["Dense_0"]["kernel"] + p["Dense_0"]["bias"]
+
+    def apply_fn(variables, x, train=False, mutable=False, **_):
+        th = torch.cat([_get(variables["params"], pth).reshape(-1) for pth, _ in layout])
+        return forward(th, x) if x.dim() == 3 else torch.stack([forward(th, xi) for xi in x])
+
+    net = ResNet50(K, input_shape=(hw, hw, 3), stem=stem, widths=(4, 8), blocks=(1, 1))
+    st = TrainState(params={"params": _unflat(theta, layout)}, apply_fn=apply_fn, batch_stats=stats, net=net)
+    flat, _ = flatten_nn_params(st.params)
+    assert torch.equal(flat, theta)
+    Z = torch.rand(n, hw, hw, 3, generator=torch.Generator().manual_seed(53), dtype=F64)
+    assert torch.allclose(net.forward(st.params, st.batch_stats, Z), torch.stack([forward(theta, z) for z in Z]), rtol=1e-11, atol=1e-12)
+    V = _randn(54, 2, D)
+    ref, _ = _explicit_ggn_rows(forward, theta, Z, V, 7 / n)
+    vp = impl.ggn.compute_ggn_vp(impl.state(st), impl.tensor(Z), "classifier", full_set_size=7)
+    Y = impl.rows(vp, impl.tensor(V))
+    assert (cpu64(Y) - ref).abs().max().item() <= impl.tol(1e-11, 3e-5) * ref.abs().max().item()
