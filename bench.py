@@ -311,15 +311,9 @@ def main():
     other_ms = sum(ms for k, (ms, c) in prof.items() if k not in kinds) / prof_steps
     dom = "igemm_kernel"
     achieved = per_kernel[dom]["tflops"]
+    # HBM bytes per launch are NOT measured inside this run (the PMC passes need rocprofv3 around the process): null here;
+    # the committed counter passes of this same command are profiles/r3_traffic.json (scripts/profile.sh)
     traffic = None
-    try:                       # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
-        tj_path = next(pth for pth in (os.path.join(ROOT, "profiles", f) for f in ("r2_traffic.json", "r1_traffic.json")) if os.path.exists(pth))
-        tj = json.load(open(tj_path))["kernels"]
-        sel = [v for k, v in tj.items() if "igemm" in k]
-        traffic = dict(value=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / sum(v["launches"] for v in sel),
-                       unit="bytes per igemm launch (2 x FETCH_SIZE + WRITE_SIZE)", source=os.path.relpath(tj_path, ROOT))
-    except Exception:
-        pass
     roofline = dict(bound="mfma", kernel=dom + " (tangent-forward + data-gradient implicit GEMMs, f32 MFMA)",
                     achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TFLOPS,
                     traffic=traffic, per_kernel=per_kernel, other_kernels_ms_per_step=other_ms,

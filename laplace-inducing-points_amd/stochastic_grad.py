@@ -189,13 +189,33 @@ def _hutchpp_value_and_terms(S_rows, WT_rows, W_rows, Minv, alpha, probes, s1, s
 # SLQ on the bidiagonalisation of A v = [sqrt(alpha) v ; s_b W^T v]: value and cotangent of W
 # ----------------------------------------------------------------------------------------------------------------
 def _slq_small(alphas, betas, len2):
-    """mean_p ||p||^2 e1^T log(B^T B) e1 for upper-bidiagonal B (P, k, k) — differentiable float64 torch."""
+    """mean_p ||p||^2 e1^T log(B^T B) e1 for upper-bidiagonal B (P, k, k), float64, and its gradient w.r.t. the two
+    diagonals — in closed form (Daleckii-Krein): with T = B^T B = U diag(ev) U^T and u = U^T e1,
+
+        d (e1^T log(T) e1) = < Phi, dT >,   Phi = U (F o u u^T) U^T,   F_ij = (log ev_i - log ev_j) / (ev_i - ev_j),  F_ii = 1 / ev_i,
+
+    dT = dB^T B + B^T dB  =>  d / dB = 2 B Phi.  Differentiating ``eigh`` itself (autograd) divides by ev_i - ev_j, and
+    a Lanczos run that has converged on part of the spectrum delivers clustered Ritz values: NaN at the CIFAR config
+    (k = 40).  The divided difference of log is smooth: for close pairs it is evaluated as log1p(x) / x / ev_j, exact
+    to rounding for every separation."""
     Bm = torch.diag_embed(alphas)
     if betas.shape[-1] > 0:
         Bm = Bm + torch.diag_embed(betas, 1)
     T = Bm.transpose(-1, -2) @ Bm
     ev, U = torch.linalg.eigh(T)
-    return (len2 * (U[:, 0, :] ** 2 * torch.log(ev)).sum(-1)).mean()
+    ev = ev.clamp_min(1e-300)
+    u = U[:, 0, :]                                               # (P, k) = e1^T U
+    vals = (u * u * torch.log(ev)).sum(-1)
+    value = (len2 * vals).mean()
+    x = ev[:, :, None] / ev[:, None, :] - 1.0                    # ev_i / ev_j - 1
+    safe = torch.where(x.abs() < 1e-300, torch.ones_like(x), x)
+    F = torch.where(x.abs() < 1e-300, torch.ones_like(x), torch.log1p(safe) / safe) / ev[:, None, :]
+    F = 0.5 * (F + F.transpose(-1, -2))
+    Phi = U @ (F * (u[:, :, None] * u[:, None, :])) @ U.transpose(-1, -2)
+    G = 2.0 * (Bm @ Phi) * (len2 / len2.shape[0])[:, None, None]
+    gal = torch.diagonal(G, dim1=-2, dim2=-1).clone()
+    gbe = torch.diagonal(G, offset=1, dim1=-2, dim2=-1).clone() if betas.shape[-1] > 0 else torch.zeros_like(betas)
+    return value, gal, gbe
 
 
 def _slq_value_and_terms(WT_rows, W_rows, D, d, alpha, s_b, probes, k, vec):
@@ -211,12 +231,8 @@ def _slq_value_and_terms(WT_rows, W_rows, D, d, alpha, s_b, probes, k, vec):
     P = probes.shape[0]
     len2 = vec.bdot(probes, probes)
     al, be, Vb, Ub = vec.bidiag(A, AT, probes, k, D + d)
-    al64 = al.double().detach().clone().requires_grad_(True)
-    be64 = be.double().detach().clone().requires_grad_(True)
-    val = _slq_small(al64, be64, len2.to(al64.device))
-    gal, gbe = torch.autograd.grad(val, (al64, be64), allow_unused=True)
-    gbe = torch.zeros_like(be64) if gbe is None else gbe
-    al64, be64 = al64.detach(), be64.detach()
+    al64, be64 = al.double(), be.double()
+    val, gal, gbe = _slq_small(al64, be64, len2.to(al64.device))
     # ---- reverse mode over  alpha_j u_j = A v_j - beta_{j-1} u_{j-1} ;  beta_j v_{j+1} = A^T u_j - alpha_j v_j
     dev = probes.device
     zero_u = lambda: torch.zeros(P, D + d, dtype=dt, device=dev)
@@ -257,7 +273,7 @@ def _slq_value_and_terms(WT_rows, W_rows, D, d, alpha, s_b, probes, k, vec):
             ubar[j - 1] = contrib if ubar[j - 1] is None else vec.lin([(1.0, ubar[j - 1]), (1.0, contrib)])
         ubar[j] = None
         vbar_next = vbar_j
-    return float(val.detach()), terms
+    return float(val), terms
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -32,3 +32,7 @@ print(f"pass 1 lip_gemm_nt        {t1:7.3f} ms {fl / t1 / 1e9:6.1f} TF")
 print(f"stiff  lip_dot_nt_f64 (96) {t2:7.3f} ms {2.0 * S * 96 * D / t2 / 1e9:6.1f} TF (f64)")
 print(f"pass 2 lip_gemm_nn_axpy   {t3:7.3f} ms {fl / t3 / 1e9:6.1f} TF")
 print(f"pass 2 torch.addmm        {t4:7.3f} ms {fl / t4 / 1e9:6.1f} TF   max diff {((mine - ref).abs().max() / ref.abs().max()).item():.2e}")
+Vc = V.clone()
+t5 = timed(lambda: krylov.gemm_nn_axpy(T, Qm, Vc, 1.0, out=Vc))
+t6 = timed(lambda: torch.addmm(Vc, T, Qm, beta=1.0, out=Vc))
+print(f"pass 2 in place: lip_gemm_nn_axpy {t5:7.3f} ms, torch.addmm {t6:7.3f} ms")
