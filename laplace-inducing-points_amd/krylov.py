@@ -389,7 +389,8 @@ def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: 
     the domain: A V = U B with B (k, k) upper bidiagonal (matfree ``decomp.bidiag`` as the reference calls it,
     ``src/train_inducing.py:156``).  ``matvec``: (P, N) -> (P, n_out); ``vecmat``: (P, n_out) -> (P, N).
     Returns (alphas (P, k), betas (P, k-1)) and, with ``return_bases``, the bases V (P, k, N) and U (P, k, n_out)
-    (views of the padded storage) that the adjoint recurrence of ``stochastic_grad.py`` walks back over."""
+    (views of the padded storage) and the projection coefficients of the two Gram-Schmidt passes of every step
+    ((cu1, cu2, cv1, cv2), each (P, k, k)) — what the adjoint recurrence of ``stochastic_grad.py`` walks back over."""
     lib = nv.load()
     P, N = _chk(V0).shape
     st = nv.stream_ptr()
@@ -400,6 +401,7 @@ def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: 
     betas = torch.zeros(P, max(k - 1, 0), device=dev, dtype=torch.float32)
     c1 = torch.empty(P, k, device=dev, dtype=torch.float32)
     c2 = torch.empty(P, k, device=dev, dtype=torch.float32)
+    coef = [torch.zeros(P, k, k, device=dev, dtype=torch.float32) for _ in range(4)] if return_bases else None   # cu1, cu2, cv1, cv2
     nrm2 = bdot(V0, V0)
     nv.check(lib.lip_scale_store(nv.ptr(V0), nv.ptr(nrm2), nv.ptr(Vb), 0, P, k, N, ldv, st), "lip_scale_store")
     for j in range(k):
@@ -407,6 +409,8 @@ def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: 
         u = _chk(matvec(v).contiguous())
         if j > 0:
             _cgs2(lib, Ub, ldu, u, P, j, k, n_out, c1, c2, nrm2, st)
+            if coef is not None:
+                coef[0][:, j, :j], coef[1][:, j, :j] = c1[:, :j], c2[:, :j]
         else:
             nrm2 = bdot(u, u)
         alphas[:, j] = torch.sqrt(nrm2)
@@ -414,10 +418,12 @@ def bidiag(matvec: Callable, vecmat: Callable, V0: torch.Tensor, k: int, n_out: 
         if j + 1 < k:
             w = _chk(vecmat(Ub[:, j, :n_out].contiguous()).contiguous())
             _cgs2(lib, Vb, ldv, w, P, j + 1, k, N, c1, c2, nrm2, st)
+            if coef is not None:
+                coef[2][:, j, :j + 1], coef[3][:, j, :j + 1] = c1[:, :j + 1], c2[:, :j + 1]
             betas[:, j] = torch.sqrt(nrm2)
             nv.check(lib.lip_scale_store(nv.ptr(w), nv.ptr(nrm2), nv.ptr(Vb), j + 1, P, k, N, ldv, st), "lip_scale_store")
     if return_bases:
-        return alphas, betas, Vb[:, :, :N], Ub[:, :, :n_out]
+        return alphas, betas, Vb[:, :, :N], Ub[:, :, :n_out], tuple(coef)
     return alphas, betas
 
 

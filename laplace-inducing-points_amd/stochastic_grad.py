@@ -32,10 +32,10 @@ gradient does not depend on which QR produced Q (the reference's Householder QR,
 to the cotangent of W (the dependence of M^-1 on W^T W included) — every vector on the left already exists in the
 forward / adjoint pass.
 
-SLQ.  Full re-orthogonalisation is the identity in exact arithmetic for EVERY operator, so the estimator is the same
-function of W as the plain Golub-Kahan recurrence  alpha_j u_j = A v_j - beta_{j-1} u_{j-1},  beta_j v_{j+1} = A^T u_j -
-alpha_j v_j, and reverse mode runs over that recurrence with the (re-orthogonalised) stored bases: one application of A
-and one of A^T per step, two rank-one terms per step.
+SLQ.  Reverse mode runs over the Golub-Kahan recurrence exactly as it ran, re-orthogonalisation passes included (their
+projection coefficients are kept by the forward pass): one application of A and one of A^T per step, two rank-one
+terms per step.  Transposing only the plain three-term recurrence would give the same gradient in exact arithmetic
+(the passes are then the identity) but an unstable backward recurrence: measured and rejected, see the code.
 
 The D-sized linear algebra is behind a small vector backend: :class:`HipVec` (``lip_dot_nt_f64``, ``lip_rows_combine``,
 ``lip_bdot``, ``lip_axpby`` — the product path) and :class:`TorchVec` (plain torch, any dtype / device: used by the CPU
@@ -78,32 +78,51 @@ class TorchVec:
         return Qc.T.contiguous(), Cm.double()
 
     def bidiag(self, matvec, vecmat, V0, k, n_out):
-        """Golub-Kahan with full re-orthogonalisation, P recurrences at once: (alphas, betas, V (P,k,N), U (P,k,n_out))."""
+        """Golub-Kahan with full re-orthogonalisation (classical Gram-Schmidt twice against ALL previous vectors), P
+        recurrences at once: (alphas, betas, V (P,k,N), U (P,k,n_out), coeffs) with coeffs = (cu1, cu2, cv1, cv2), each
+        (P, k, k): row j holds the projection coefficients the two passes of step j took out (the adjoint needs them)."""
         P, N = V0.shape
-        V = torch.zeros(P, k, N, dtype=V0.dtype, device=V0.device)
-        U = torch.zeros(P, k, n_out, dtype=V0.dtype, device=V0.device)
-        al = torch.zeros(P, k, dtype=V0.dtype, device=V0.device)
-        be = torch.zeros(P, max(k - 1, 0), dtype=V0.dtype, device=V0.device)
+        kw = dict(dtype=V0.dtype, device=V0.device)
+        V, U = torch.zeros(P, k, N, **kw), torch.zeros(P, k, n_out, **kw)
+        al, be = torch.zeros(P, k, **kw), torch.zeros(P, max(k - 1, 0), **kw)
+        cu1, cu2, cv1, cv2 = (torch.zeros(P, k, k, **kw) for _ in range(4))
         v = V0 / V0.norm(dim=1, keepdim=True)
         for j in range(k):
             V[:, j] = v
             u = matvec(v)
-            for _ in range(2):
-                u = u - torch.einsum("pk,pkn->pn", torch.einsum("pkn,pn->pk", U[:, :j], u), U[:, :j])
+            for c in (cu1, cu2):
+                c[:, j, :j] = torch.einsum("pkn,pn->pk", U[:, :j], u)
+                u = u - torch.einsum("pk,pkn->pn", c[:, j, :j], U[:, :j])
             al[:, j] = u.norm(dim=1)
             u = u / al[:, j, None]
             U[:, j] = u
             if j + 1 < k:
                 w = vecmat(u)
-                for _ in range(2):
-                    w = w - torch.einsum("pk,pkn->pn", torch.einsum("pkn,pn->pk", V[:, :j + 1], w), V[:, :j + 1])
+                for c in (cv1, cv2):
+                    c[:, j, :j + 1] = torch.einsum("pkn,pn->pk", V[:, :j + 1], w)
+                    w = w - torch.einsum("pk,pkn->pn", c[:, j, :j + 1], V[:, :j + 1])
                 be[:, j] = w.norm(dim=1)
                 v = w / be[:, j, None]
-        return al, be, V, U
+        return al, be, V, U, (cu1, cu2, cv1, cv2)
+
+    # batched Gram-Schmidt pieces of the adjoint recurrence, Q (P, j, N) a block of basis vectors
+    def proj_coeffs(self, Q, x):                            # (P, j) = Q x
+        return torch.einsum("pkn,pn->pk", Q, x)
+
+    def sub_combination(self, x, c, Q):                     # x - c Q
+        return x - torch.einsum("pk,pkn->pn", c.to(x.dtype), Q)
+
+    def add_combination(self, x, c, Q):                     # x + c Q
+        return x + torch.einsum("pk,pkn->pn", c.to(x.dtype), Q)
+
+    def rank1_update_(self, Bar, a, x):                     # Bar (P, j, N) -= a (P, j) (x) x (P, N)
+        Bar.baddbmm_(a.to(x.dtype)[:, :, None], x[:, None, :], alpha=-1.0)
 
 
-class HipVec:
-    """The product backend: every D-sized operation is a kernel of ``csrc/lip_krylov.hip``."""
+class HipVec(TorchVec):
+    """The product backend: the D-sized operations are kernels of ``csrc/lip_krylov.hip``; the batched Gram-Schmidt
+    pieces of the SLQ adjoint (projection coefficients against / rank-one updates of a (P, j, N) block of basis
+    vectors: HBM-bound batched GEMV / GER) run as torch batched products on the device."""
 
     def __init__(self):
         from . import krylov
@@ -138,7 +157,7 @@ class HipVec:
         return self.k.gram_orthonormalize(Y.contiguous(), return_transform=True)
 
     def bidiag(self, matvec, vecmat, V0, k, n_out):
-        return self.k.bidiag(matvec, vecmat, V0.contiguous(), k, n_out, return_bases=True)
+        return self.k.bidiag(matvec, vecmat, V0.contiguous(), k, n_out, return_bases=True)     # (..., V, U, coefficients)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -230,49 +249,51 @@ def _slq_value_and_terms(WT_rows, W_rows, D, d, alpha, s_b, probes, k, vec):
 
     P = probes.shape[0]
     len2 = vec.bdot(probes, probes)
-    al, be, Vb, Ub = vec.bidiag(A, AT, probes, k, D + d)
+    al, be, Vb, Ub, (cu1, cu2, cv1, cv2) = vec.bidiag(A, AT, probes, k, D + d)
     al64, be64 = al.double(), be.double()
     val, gal, gbe = _slq_small(al64, be64, len2.to(al64.device))
-    # ---- reverse mode over  alpha_j u_j = A v_j - beta_{j-1} u_{j-1} ;  beta_j v_{j+1} = A^T u_j - alpha_j v_j
-    dev = probes.device
-    zero_u = lambda: torch.zeros(P, D + d, dtype=dt, device=dev)
-    ubar = [None] * k                           # cotangents of u_j (filled lazily)
-    vbar_next = None                            # cotangent of v_{j+1}
-    bbar_extra = torch.zeros(P, dtype=torch.float64, device=dev)   # contribution to betabar_j from uhat_{j+1}
+    # ---- reverse mode over the recurrence AS IT RAN: per step  u0 = A v_j, two Gram-Schmidt passes against U_{<j},
+    # u_j = u2 / alpha_j;  w0 = A^T u_j, two passes against V_{<=j}, v_{j+1} = w2 / beta_j.  The adjoint of a pass
+    # y = x - sum_i (q_i . x) q_i is  xbar = ybar - sum_i (q_i . ybar) q_i  and  qbar_i -= (q_i . x) ybar + (q_i . ybar) x.
+    # (Dropping the passes — they are the identity in exact arithmetic, so the FUNCTION is that of the plain three-term
+    # recurrence — gives an adjoint recurrence that amplifies rounding by ~10x per step: 0.19 off at k = 20 in float64
+    # and overflow at k = 30, NaN at the CIFAR config's k = 40; with the passes transposed it is as stable as reverse
+    # mode through the re-orthogonalised algorithm: 4e-4 in float32 at k = 30, same toy — scripts/slq_adjoint_stability.py.)
+    Ubar, Vbar = torch.zeros_like(Ub), torch.zeros_like(Vb)
     terms: List[Tuple[torch.Tensor, torch.Tensor]] = []
+
+    def pass_adjoint(Q, Qbar, ybar, c, x_in):
+        """one Gram-Schmidt pass y = x_in - c Q, c = Q x_in: returns xbar and updates the basis cotangents Qbar"""
+        t = vec.proj_coeffs(Q, ybar)
+        vec.rank1_update_(Qbar, c, ybar)
+        vec.rank1_update_(Qbar, t, x_in)
+        return vec.sub_combination(ybar, t, Q)
+
     for j in range(k - 1, -1, -1):
-        vj, uj = Vb[:, j, :D].contiguous(), Ub[:, j, :D + d].contiguous()
-        vbar_j = None
-        abar = gal[:, j].clone()
+        vj, uj = Vb[:, j], Ub[:, j]
         if j + 1 < k:
-            vn = Vb[:, j + 1, :D].contiguous()
-            bj = be64[:, j]
-            bbar = gbe[:, j] + bbar_extra
-            if vbar_next is None:
-                what = vec.lin([(bbar, vn)])
-            else:
-                proj = vec.bdot(vn, vbar_next)
-                what = vec.lin([(1.0 / bj, vbar_next), (bbar - proj / bj, vn)])
-            # w_j = A^T u_j - alpha_j v_j
-            Aw = A(what)
-            ubar[j] = Aw if ubar[j] is None else vec.lin([(1.0, ubar[j]), (1.0, Aw)])
-            terms.append((what, s_b * uj[:, D:].double()))
-            abar = abar - vec.bdot(what, vj)
-            vbar_j = vec.lin([(-al64[:, j], what)])
-        ub = ubar[j] if ubar[j] is not None else zero_u()
-        # u_j = uhat_j / alpha_j
-        uhat = vec.lin([(1.0 / al64[:, j], ub), (abar - vec.bdot(uj, ub) / al64[:, j], uj)])
-        # uhat_j = A v_j - beta_{j-1} u_{j-1}
-        back = AT(uhat)
-        vbar_j = back if vbar_j is None else vec.lin([(1.0, vbar_j), (1.0, back)])
-        terms.append((vj, s_b * uhat[:, D:].double()))
+            vn, bj = Vb[:, j + 1], be64[:, j]
+            vb = Vbar[:, j + 1]
+            w2bar = vec.lin([(1.0 / bj, vb), (gbe[:, j] - vec.bdot(vn, vb) / bj, vn)])
+            Q, Qbar = Vb[:, :j + 1], Vbar[:, :j + 1]
+            w1 = vec.add_combination(vec.lin([(bj, vn)]), cv2[:, j, :j + 1], Q)          # input of the second pass
+            w0 = vec.add_combination(w1, cv1[:, j, :j + 1], Q)                             # input of the first pass
+            w1bar = pass_adjoint(Q, Qbar, w2bar, cv2[:, j, :j + 1], w1)
+            w0bar = pass_adjoint(Q, Qbar, w1bar, cv1[:, j, :j + 1], w0)
+            Ubar[:, j] += A(w0bar)                                                          # w0 = A^T u_j
+            terms.append((w0bar, s_b * uj[:, D:].double()))
+        ub = Ubar[:, j]
+        u2bar = vec.lin([(1.0 / al64[:, j], ub), (gal[:, j] - vec.bdot(uj, ub) / al64[:, j], uj)])
         if j > 0:
-            up = Ub[:, j - 1, :D + d].contiguous()
-            bbar_extra = -vec.bdot(uhat, up)
-            contrib = vec.lin([(-be64[:, j - 1], uhat)])
-            ubar[j - 1] = contrib if ubar[j - 1] is None else vec.lin([(1.0, ubar[j - 1]), (1.0, contrib)])
-        ubar[j] = None
-        vbar_next = vbar_j
+            Q, Qbar = Ub[:, :j], Ubar[:, :j]
+            u1 = vec.add_combination(vec.lin([(al64[:, j], uj)]), cu2[:, j, :j], Q)
+            u0 = vec.add_combination(u1, cu1[:, j, :j], Q)
+            u1bar = pass_adjoint(Q, Qbar, u2bar, cu2[:, j, :j], u1)
+            u0bar = pass_adjoint(Q, Qbar, u1bar, cu1[:, j, :j], u0)
+        else:
+            u0bar = u2bar
+        Vbar[:, j] += AT(u0bar.contiguous())                                                # u0 = A v_j
+        terms.append((vj.contiguous(), s_b * u0bar[:, D:].double()))
     return float(val), terms
 
 
