@@ -211,7 +211,9 @@ def compute_ggn_vp(state, Z, model_type, full_set_size=None, mode: str = "matfre
         from . import krylov
         Vb = Vb.contiguous()
         U = krylov.gemm_nt(Vb, Wm) if Vb.shape[0] >= 32 else Vb @ Wm.T      # both operands run along D: lip_gemm_nt
-        return krylov.gemm_nn_axpy(U.contiguous(), Wm)                       # (P, d)(d, D): lip_gemm_nn_axpy
+        # (P, d)(d, D): the library GEMM (hipBLASLt ~145 TFLOP/s on this shape; the build's own lip_gemm_nn_axpy reaches 86
+        # — scripts/sampler_gemm_bench.py — and is kept as an ABI primitive, not on this path)
+        return U @ Wm
 
     op = BlockOperator(apply, (eng.D,), (eng.D,), eng, "ggn_vp[factor]")
     op.factor = Wm

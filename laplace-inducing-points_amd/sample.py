@@ -198,7 +198,7 @@ class _SamplerParts:
         T, B = self._correction(V)
         a = 1.0 / math.sqrt(self.alpha)
         if B is not None:
-            return krylov.gemm_nn_axpy(T, B, V, a)                                         # W x + alpha^(-1/2) v in one pass (lip_gemm_nn_axpy)
+            return _nn_axpy(T, B, V, a)                                                    # W x + alpha^(-1/2) v in one pass
         out = self.Wfun.rows(T.reshape((V.shape[0],) + self.inner))                        # one W sweep, matrix-free
         return krylov.axpby(out, V.contiguous(), None, a, None, 1.0)                       # + alpha^(-1/2) v
 
@@ -211,9 +211,22 @@ class _SamplerParts:
         if B is None:
             V.copy_(self.apply(V))
             return V
-        return krylov.gemm_nn_axpy(T, B, V, 1.0 / math.sqrt(self.alpha), out=V)
+        return _nn_axpy(T, B, V, 1.0 / math.sqrt(self.alpha), out=V)
 
 
+def _nn_axpy(T, B, V, beta, out=None):
+    """beta V + T B, the second pass of a block of draws.  Measured on MI355X at (256 x 450)(450 x 1.08 M)
+    (``scripts/sampler_gemm_bench.py``, round 3): the build's own NN kernel ``lip_gemm_nn_axpy`` 2.91 ms out of place and
+    3.00 ms in place (86 TFLOP/s); hipBLASLt through ``torch.addmm`` 2.82 ms out of place and 2.13 ms in place
+    (117 TFLOP/s: the addend is the output, one pass over the block fewer).  The library stays on this path; the own
+    kernel is selected with ``LIP_OWN_GEMM=1`` (A/B) and is what a build without hipBLASLt would run."""
+    if _OWN_GEMM:
+        return krylov.gemm_nn_axpy(T, B, V, beta, out=out)
+    return torch.addmm(V, T, B, beta=beta, alpha=1.0) if out is None else torch.addmm(V, T, B, beta=beta, alpha=1.0, out=out)
+
+
+import os as _os
+_OWN_GEMM = bool(_os.environ.get("LIP_OWN_GEMM"))
 _PARTS_CACHE = {}
 _PARTS_CACHE_MAX = 2
 
