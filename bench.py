@@ -569,7 +569,7 @@ def main():
     if args.samples > 0 and rank == 0 and world == 1:
         from lip_amd.sample import range_deflation
         Bc = krylov.fill_normal(16, eng.D, 77, dev)
-        cg_line = dict(rhs=16, tol=1e-3, maxiter=200,
+        cg_line = dict(rhs=16, tol=1e-3, maxiter=200, stall_guard_deflated=3,
                        note="iterations of the float32 recurrence (JAX's stopping rule, per right-hand side), the TRUE relative "
                             "residual ||A x - b|| / ||b|| afterwards (evaluated in the invariant subspaces range(W) / complement: "
                             "through the raw float32 product it is swamped by eps ||A|| ||x||), wall seconds; deflated = "
@@ -582,7 +582,7 @@ def main():
             Acg = lambda Vb, a=a_cg: eng.ggn_vp(Vb.contiguous(), scale, a)
             defl = range_deflation(st_l, Zl, eng.D, a_cg, "classifier", full)
             for tag, solver in (("plain", lambda: krylov.cg(Acg, Bc, tol=1e-3, maxiter=200, check_every=10)),
-                                ("deflated", lambda: krylov.cg_deflated(Acg, Bc, defl, tol=1e-3, maxiter=200))):
+                                ("deflated", lambda: krylov.cg_deflated(Acg, Bc, defl, tol=1e-3, maxiter=200, stall=3))):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 Xc, info_c = solver()

@@ -310,10 +310,15 @@ def funm_lanczos_dense(dense_funm: Callable, num_matvecs: int):
 
 
 def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[torch.Tensor] = None, tol: float = 1e-5,
-       atol: float = 0.0, maxiter: Optional[int] = None, check_every: int = 1):
+       atol: float = 0.0, maxiter: Optional[int] = None, check_every: int = 1, stall: Optional[int] = None):
     """Batched conjugate gradients, one independent solve per row of B (P, N), with JAX's defaults and
     stopping rule (||r||^2 <= max(tol^2 ||b||^2, atol^2), maxiter = 10 N).  Returns ``(X, info)`` where
-    info holds the iteration count and final residual norms (the reference discards it)."""
+    info holds the iteration count and final residual norms (the reference discards it).
+
+    ``stall`` (not in JAX): a right-hand side whose recurrence residual has not dropped by 10 % below its best value for
+    ``stall`` consecutive iterations is frozen — a float32 recurrence that has reached the noise floor of its operator
+    only accumulates rounding when iterated further (forward error 8e-3 after 5 steps, 8e-2 after 200 at the CIFAR
+    config's alpha = 0.005, deflated operator)."""
     lib = nv.load()
     B = _chk(B.contiguous())
     P, N = B.shape
@@ -327,6 +332,7 @@ def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[
     atol2 = torch.clamp(tol * tol * bdot(B, B), min=atol * atol)
     active = (rr > atol2).to(torch.int32)
     rr_new = torch.empty_like(rr)
+    best, since = rr.clone(), torch.zeros_like(active)
     it = 0
     while it < maxiter:
         if it % check_every == 0 and not bool(active.any()):
@@ -339,6 +345,10 @@ def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[
                  "lip_cg_direction")
         rr = torch.where(active.bool(), rr_new, rr)
         active = (rr > atol2).to(torch.int32) * active
+        if stall is not None:
+            since = torch.where(rr < 0.81 * best, torch.zeros_like(since), since + 1)
+            best = torch.minimum(best, rr)
+            active = active * (since < int(stall)).to(torch.int32)
         it += 1
     return X, dict(iterations=it, residual_norm=torch.sqrt(rr))
 
