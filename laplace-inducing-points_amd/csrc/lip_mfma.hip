@@ -1759,6 +1759,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNtP prm) {
   }
 }
 
+// (Round 3, measured and removed: the same product with BOTH operands straight from global memory into the MFMA operand
+// registers — lane-half h holding the contiguous k's 8h .. 8h+7 of its row of A and of B, no LDS, no barrier, 2 x 2 waves
+// of 64 x 64 per block, register tiles three deep: 3.90 ms = 64 TFLOP/s on (256 x D)(450 x D)^T against 2.98 ms = 84 of
+// the LDS-staged kernel above.  Every lane's 16-byte load is a request of its own at the L1 — rows are D floats apart —
+// and with two direct operands a CU issues one request per cycle: the tag pipeline, not the matrix pipe, sets the pace.)
 hipError_t launch_gemm_nt(const float* A, long long lda, int m, const float* B, long long ldb, int n, long long K, float* C,
                           hipStream_t st) {
   GemmNtP p;
