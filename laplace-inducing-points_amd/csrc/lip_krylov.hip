@@ -8,6 +8,7 @@
 // (src/stochtrace.py:30-34).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include "lip_internal.h"
 
@@ -337,6 +338,108 @@ __global__ __launch_bounds__(256) void dot_nt_f64_kernel(const float* __restrict
   }
 }
 
+// The same 32 x 32 x K-range block on the float64 matrix pipe (round 3): v_mfma_f64_16x16x4_f64, operands straight from
+// global memory — lane (i = lane & 15, q = lane >> 4) loads the four consecutive k's 4q .. 4q+3 of its row as ONE 16-byte
+// load per operand tile and 16-deep chunk (16 rows x 64 contiguous bytes per instruction) and k-step s of the chunk
+// multiplies element s of every lane's quad (A and B agree on that choice, so the sum over the chunk is unchanged);
+// converted to float64 in registers.  No LDS in the loop, no barrier: the four waves of a block take every fourth
+// chunk of the block's K-range and meet in LDS at the end, exactly where the VALU kernel's waves do.  The VALU kernel
+// reads 2 B of LDS per FLOP (a 4 x 4 micro-tile per lane) — half the LDS bandwidth at the float64 peak.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void dot_nt_f64_mfma_kernel(const float* __restrict__ A, long long lda, int m,
+                                                              const float* __restrict__ B, long long ldb, int n, long long K,
+                                                              long long kper, double* __restrict__ C, double* __restrict__ part) {
+  __shared__ double red[3 * DT_B * DT_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int tiles_n = (n + DT_B - 1) / DT_B;
+  const int m0 = (blockIdx.x / tiles_n) * DT_B, n0 = (blockIdx.x % tiles_n) * DT_B;
+  const long long kb = (long long)blockIdx.y * kper, ke = (kb + kper < K) ? kb + kper : K;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // rows clamped (outputs past m / n are never written), this lane's quad at k = chunk + 4 q
+  const float* ap[2];
+  const float* bp[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    ap[t] = A + (long long)min(m0 + 16 * t + i16, m - 1) * lda + 4 * q;
+    bp[t] = B + (long long)min(n0 + 16 * t + i16, n - 1) * ldb + 4 * q;
+  }
+  auto fetch = [&](long long k0, float (&ra)[2][4], float (&rb)[2][4]) __attribute__((always_inline)) {
+    if (k0 + 16 <= ke) {                                      // whole chunk (uniform): unconditional 16-byte loads
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f4u va = *reinterpret_cast<const f4u*>(ap[t] + k0);
+        const f4u vb = *reinterpret_cast<const f4u*>(bp[t] + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ra[t][e] = va[e]; rb[t][e] = vb[e]; }
+      }
+    } else {                                                  // the last, partial chunk of the K-range: element loads
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = k0 + 4 * q + e < ke;
+          ra[t][e] = ok ? ap[t][k0 + e] : 0.f;
+          rb[t][e] = ok ? bp[t][k0 + e] : 0.f;
+        }
+    }
+  };
+  auto sweep = [&](const float (&ra)[2][4], const float (&rb)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double a0 = (double)ra[0][e], a1 = (double)ra[1][e], b0 = (double)rb[0][e], b1 = (double)rb[1][e];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+  float ra0[2][4], rb0[2][4], ra1[2][4], rb1[2][4];
+  long long k0 = kb + 16ll * wave;                            // this wave's chunks: every fourth one of the K-range
+  if (k0 < ke) fetch(k0, ra0, rb0);
+  while (k0 < ke) {
+    const long long k1 = k0 + 64;
+    if (k1 < ke) fetch(k1, ra1, rb1);
+    sweep(ra0, rb0);
+    if (k1 >= ke) break;
+    const long long k2 = k1 + 64;
+    if (k2 < ke) fetch(k2, ra0, rb0);
+    sweep(ra1, rb1);
+    k0 = k2;
+  }
+  // C/D map of v_mfma_f64_16x16x4_f64: register r of lane l holds (row = (l >> 4) + 4 r, col = l & 15)
+  if (wave > 0) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave - 1) * DT_B * DT_B + (16 * tm + q + 4 * r) * DT_B + 16 * tn + i16] = acc[tm][tn][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double* mine = part ? part + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (DT_B * DT_B) : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = (16 * tm + q + 4 * r) * DT_B + 16 * tn + i16;
+          const double v = acc[tm][tn][r] + red[e] + red[DT_B * DT_B + e] + red[2 * DT_B * DT_B + e];
+          const int row = m0 + 16 * tm + q + 4 * r, col = n0 + 16 * tn + i16;
+          if (mine) mine[e] = v;
+          else if (row < m && col < n) unsafeAtomicAdd(C + (long long)row * n + col, v);
+        }
+  }
+}
+
 // second stage: C[r][c] = sum over the K-ranges of the partial tiles.  One block per 64 elements of a tile, sixteen
 // waves each summing every sixteenth partial (coalesced 512-byte reads), LDS for the last step — a serial loop over
 // hundreds of partials per thread would be latency-bound (measured: 190 us for 768 partials of one tile).
@@ -631,8 +734,13 @@ int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64
   // tiles than it holds or no buffer is to be had
   double* part = (ks > 1 && tiles * ks <= DT_SCRATCH_TILES) ? dot_nt_scratch(st) : nullptr;
   if (!part) LIP_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(double) * (size_t)m * n, st));
-  hipLaunchKernelGGL(dot_nt_f64_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
-                     (long long)ldb, n, (long long)K, kper, C, part);
+  static const bool valu = getenv("LIP_DOT_NT_VALU") != nullptr;          // A/B switch: the VALU / LDS kernel
+  if (valu)
+    hipLaunchKernelGGL(dot_nt_f64_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
+                       (long long)ldb, n, (long long)K, kper, C, part);
+  else
+    hipLaunchKernelGGL(dot_nt_f64_mfma_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
+                       (long long)ldb, n, (long long)K, kper, C, part);
   LIP_CHECK_HIP(hipGetLastError());
   if (part) {
     hipLaunchKernelGGL(dot_nt_reduce_kernel, dim3((unsigned)(tiles * 16)), dim3(1024), 0, st, part, (int)tiles, (int)ks, m, n, C);
