@@ -347,15 +347,26 @@ __global__ __launch_bounds__(256) void dot_nt_f64_kernel(const float* __restrict
 // reads 2 B of LDS per FLOP (a 4 x 4 micro-tile per lane) — half the LDS bandwidth at the float64 peak.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// QUAD: a block covers 2 x 2 tiles of 32 x 32, ONE PER WAVE, each wave over the block's whole K-range (no reduction in
+// LDS; the pairs of waves share operand rows through the L1) — taken when the output has at least 2 x 2 tiles.
+template <bool QUAD>
 __global__ __launch_bounds__(256) void dot_nt_f64_mfma_kernel(const float* __restrict__ A, long long lda, int m,
                                                               const float* __restrict__ B, long long ldb, int n, long long K,
                                                               long long kper, double* __restrict__ C, double* __restrict__ part) {
-  __shared__ double red[3 * DT_B * DT_B];
+  __shared__ double red[QUAD ? 1 : 3 * DT_B * DT_B];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
   const int tiles_n = (n + DT_B - 1) / DT_B;
-  const int m0 = (blockIdx.x / tiles_n) * DT_B, n0 = (blockIdx.x % tiles_n) * DT_B;
+  int m0, n0, tile_id;
+  if (QUAD) {
+    const int bn = (tiles_n + 1) / 2;
+    const int tm_ = 2 * ((int)blockIdx.x / bn) + (wave >> 1), tn_ = 2 * ((int)blockIdx.x % bn) + (wave & 1);
+    m0 = tm_ * DT_B; n0 = tn_ * DT_B; tile_id = tm_ * tiles_n + tn_;
+    if (m0 >= m || n0 >= n) return;                            // no tile behind this wave (odd tile counts)
+  } else {
+    m0 = ((int)blockIdx.x / tiles_n) * DT_B; n0 = ((int)blockIdx.x % tiles_n) * DT_B; tile_id = (int)blockIdx.x;
+  }
   const long long kb = (long long)blockIdx.y * kper, ke = (kb + kper < K) ? kb + kper : K;
   f64x4 acc[2][2];
 #pragma unroll
@@ -401,19 +412,36 @@ __global__ __launch_bounds__(256) void dot_nt_f64_mfma_kernel(const float* __res
     }
   };
   float ra0[2][4], rb0[2][4], ra1[2][4], rb1[2][4];
-  long long k0 = kb + 16ll * wave;                            // this wave's chunks: every fourth one of the K-range
+  constexpr long long STEP = QUAD ? 16 : 64;
+  long long k0 = QUAD ? kb : kb + 16ll * wave;                // !QUAD: this wave's chunks are every fourth one of the K-range
   if (k0 < ke) fetch(k0, ra0, rb0);
   while (k0 < ke) {
-    const long long k1 = k0 + 64;
+    const long long k1 = k0 + STEP;
     if (k1 < ke) fetch(k1, ra1, rb1);
     sweep(ra0, rb0);
     if (k1 >= ke) break;
-    const long long k2 = k1 + 64;
+    const long long k2 = k1 + STEP;
     if (k2 < ke) fetch(k2, ra0, rb0);
     sweep(ra1, rb1);
     k0 = k2;
   }
   // C/D map of v_mfma_f64_16x16x4_f64: register r of lane l holds (row = (l >> 4) + 4 r, col = l & 15)
+  if (QUAD) {
+    const int tiles = ((m + DT_B - 1) / DT_B) * tiles_n;
+    double* mine = part ? part + ((long long)blockIdx.y * tiles + tile_id) * (DT_B * DT_B) : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = (16 * tm + q + 4 * r) * DT_B + 16 * tn + i16;
+          const int row = m0 + 16 * tm + q + 4 * r, col = n0 + 16 * tn + i16;
+          if (mine) mine[e] = acc[tm][tn][r];
+          else if (row < m && col < n) unsafeAtomicAdd(C + (long long)row * n + col, acc[tm][tn][r]);
+        }
+    return;
+  }
   if (wave > 0) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -735,11 +763,28 @@ int lip_dot_nt_f64(const float* A, int64_t lda, int32_t m, const float* B, int64
   double* part = (ks > 1 && tiles * ks <= DT_SCRATCH_TILES) ? dot_nt_scratch(st) : nullptr;
   if (!part) LIP_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(double) * (size_t)m * n, st));
   static const bool valu = getenv("LIP_DOT_NT_VALU") != nullptr;          // A/B switch: the VALU / LDS kernel
+  static const bool noquad = getenv("LIP_DOT_NT_NOQUAD") != nullptr;      // A/B switch: one tile per block, waves split K
+  const int tm32 = (m + DT_B - 1) / DT_B, tn32 = (n + DT_B - 1) / DT_B;
   if (valu)
     hipLaunchKernelGGL(dot_nt_f64_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
                        (long long)ldb, n, (long long)K, kper, C, part);
-  else
-    hipLaunchKernelGGL(dot_nt_f64_mfma_kernel, dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
+  else if (!noquad && tm32 >= 2 && tn32 >= 2 && (!part || tiles * ks * 4 <= DT_SCRATCH_TILES) && chunks / (ks * 4) >= 4) {
+    // a wave per tile and K-split: four times the K-splits keep the number of waves (a wave of the other form sweeps a
+    // quarter of its block's K-range)
+    long long ks4 = ks * 4;
+    const long long kper4 = (chunks + ks4 - 1) / ks4 * DT_KC;
+    ks4 = (K + kper4 - 1) / kper4;
+    const unsigned blocks = (unsigned)(((tm32 + 1) / 2) * ((tn32 + 1) / 2));
+    hipLaunchKernelGGL((dot_nt_f64_mfma_kernel<true>), dim3(blocks, (unsigned)ks4), dim3(256), 0, st, A, (long long)lda, m, B,
+                       (long long)ldb, n, (long long)K, kper4, C, part);
+    LIP_CHECK_HIP(hipGetLastError());
+    if (part) {
+      hipLaunchKernelGGL(dot_nt_reduce_kernel, dim3((unsigned)(tiles * 16)), dim3(1024), 0, st, part, (int)tiles, (int)ks4, m, n, C);
+      LIP_CHECK_HIP(hipGetLastError());
+    }
+    return LIP_OK;
+  } else
+    hipLaunchKernelGGL((dot_nt_f64_mfma_kernel<false>), dim3((unsigned)tiles, (unsigned)ks), dim3(256), 0, st, A, (long long)lda, m, B,
                        (long long)ldb, n, (long long)K, kper, C, part);
   LIP_CHECK_HIP(hipGetLastError());
   if (part) {
