@@ -1091,6 +1091,126 @@ __global__ __launch_bounds__(256) void igemm_adirect_kernel(const IgemmP prm) {
 }
 
 // ------------------------------------------------------------------------------------------
+// first layer of a conv net (round 3): ONE K-segment with a short reduction (K = KH KW C <= 64: 3 x 3 x 3 = 27 for the
+// CIFAR nets), the A operand the PRIMAL input — shared by all probes — and 32 output columns.  The generic kernel ran it
+// at 23 TFLOP/s (0.98 ms per 256-probe block): per probe it re-gathers the same 27-deep im2col rows.  Here a wave
+// gathers the im2col rows of its 64 output rows ONCE into MFMA operand registers (lane (i = row, k = lane >> 5) of
+// k-step kk holds element 2 kk + k; zero past K), keeps the epilogue's probe-independent operands (x-hat, act') of
+// its 64 x 32 tile in registers too, and walks over the probes of its probe group: per probe 14 coalesced dword
+// loads of the weight tangent (the B operand straight into the MFMA registers), 2 x 14 MFMAs, one fused
+// BN-tangent / act' epilogue, 32 row-segment stores.  No LDS, no barrier; output-write bound.
+// ------------------------------------------------------------------------------------------
+template <int KK>
+__global__ __launch_bounds__(256) void igemm_first_kernel(const IgemmP prm, int P, int pgroups) {
+  constexpr int TM = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const SegP& sg = prm.seg[0];
+  const int R = prm.R, K = sg.Ktot;
+  const int rgroup = (int)blockIdx.x * 4 + wave;               // 64 output rows per wave
+  const int r0 = rgroup * 64;
+  if (r0 >= R) return;
+  // ---- A: im2col rows of this lane's TM rows, gathered once (rows >= R and taps outside the image read element 0 and are zeroed)
+  float areg[TM][KK];
+  const int KWC = sg.KW * sg.C;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = r0 + 32 * tm + l31;
+    const bool rv = r < R;
+    const int rc = rv ? r : 0;
+    const int i = prm.dOHW.div(rc), rem = rc - i * prm.OHW;
+    const int oh = prm.dOW.div(rem), ow = rem - oh * prm.OW;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const int k = 2 * kk + lh;
+      const int kh = k / KWC, kw = (k - kh * KWC) / sg.C, c = k - kh * KWC - kw * sg.C;
+      const int ih = oh * sg.stride + kh - sg.pad_h, iw = ow * sg.stride + kw - sg.pad_w;
+      const bool ok = rv && k < K && (unsigned)ih < (unsigned)sg.IH && (unsigned)iw < (unsigned)sg.IW;
+      const float t = sg.a[ok ? (unsigned)(((i * sg.IH + ih) * sg.IW + iw) * sg.C + c) : 0u];
+      areg[tm][kk] = ok ? t : 0.f;
+    }
+  }
+  // ---- probe-independent epilogue operands of the wave's two 32 x 32 tiles, in the accumulator layout
+  const bool has_e1 = prm.e1 != nullptr, has_d = prm.dphi != nullptr;
+  float xh[TM][16], dv[TM][16];
+  unsigned eoff[TM];                                           // element offset of accumulator register 0
+  bool full = r0 + 64 <= R;                                    // uniform
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    eoff[tm] = (unsigned)((r0 + 32 * tm + 4 * lh) * 32 + l31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = r0 + 32 * tm + 4 * lh + (q & 3) + 8 * (q >> 2);
+      const unsigned e = (unsigned)(min(r, R - 1) * 32 + l31);
+      xh[tm][q] = has_e1 ? prm.xhat[e] : 0.f;
+      dv[tm][q] = has_d ? prm.dphi[e] : 1.f;
+    }
+  }
+  const float sc = prm.scale ? prm.scale[l31] : 1.f;
+  // ---- the probes of this wave's group
+  const int pg = (int)blockIdx.y;
+  const int per = (P + pgroups - 1) / pgroups;
+  const int p_end = min(P, (pg + 1) * per);
+  const unsigned bl = (unsigned)(lh * 32 + l31);               // lane part of the B offset: row (2 kk + lh), column l31
+  auto load_b = [&](int p, float (&b)[KK]) {
+    const float* __restrict__ bp = sg.b + (long long)p * sg.b_ps;          // wave-uniform
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const bool pair = 2 * kk + 1 < K;                                     // uniform; the last k-step of an odd K reads row K - 1 (A is zero there)
+      b[kk] = (bp + (pair ? 2 * kk * 32 : (2 * kk < K ? (K - 1) * 32 : 0)))[pair ? bl : (unsigned)l31];
+    }
+  };
+  int p = pg * per;
+  if (p >= p_end) return;
+  float b[KK], bn[KK];
+  load_b(p, b);
+  for (; p < p_end; ++p) {
+    load_b(min(p + 1, p_end - 1), bn);
+    const float e0v = prm.e0 ? prm.e0[(long long)p * prm.e0_ps + l31] : 0.f;
+    const float e1v = has_e1 ? prm.e1[(long long)p * prm.e1_ps + l31] : 0.f;
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[tm][q] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tm][kk], b[kk], acc[tm], 0, 0, 0);
+    float* __restrict__ out = prm.out + (long long)p * prm.out_ps;          // wave-uniform
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float v = (acc[tm][q] * sc + e0v + e1v * xh[tm][q]) * dv[tm][q];
+        if (full || r0 + 32 * tm + 4 * lh + (q & 3) + 8 * (q >> 2) < R) (out + ((q & 3) + 8 * (q >> 2)) * 32)[eoff[tm]] = v;
+      }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) b[kk] = bn[kk];
+  }
+}
+
+static bool igemm_first_ok(const IgemmP& p, int P) {
+  static const bool off = getenv("LIP_NOFIRST") != nullptr || getenv("LIP_GENERIC") != nullptr;        // A/B switch
+  if (off || precision_mode() != 0 || p.nseg != 1 || P < 8) return false;
+  const SegP& s = p.seg[0];
+  return s.mode == 0 && s.Ktot <= 64 && (s.C & 15) != 0 && p.N == 32 && s.a_ps == 0 && !s.b_trans && !p.res && !p.red0 &&
+         !p.red1 && (!p.e1 || p.xhat) && (long long)p.R * 32 < (1ll << 31);
+}
+
+static hipError_t run_igemm_first(const IgemmP& p, int P, hipStream_t st) {
+  const int rblocks = (p.R + 255) / 256;                                     // 4 waves x 64 rows
+  int pgroups = (int)((8ll * 256 * 4 / 4 + rblocks - 1) / rblocks);          // ~8 waves per SIMD's worth of wave items over the chip
+  if (pgroups > P / 8) pgroups = P / 8;                                      // >= 8 probes per wave amortise its A / x-hat / act' gathers
+  if (pgroups < 1) pgroups = 1;
+  dim3 grid((unsigned)rblocks, (unsigned)pgroups);
+  if (p.seg[0].Ktot <= 28) hipLaunchKernelGGL((igemm_first_kernel<14>), grid, dim3(256), 0, st, p, P, pgroups);
+  else hipLaunchKernelGGL((igemm_first_kernel<32>), grid, dim3(256), 0, st, p, P, pgroups);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN>
@@ -2146,6 +2266,7 @@ static int cu_count() {
 }
 
 hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
+  if (igemm_first_ok(p, P)) return run_igemm_first(p, P, st);
   // Few probes (single-vector Krylov loops): with fewer 128-row blocks than CUs the launch time is ONE block's K loop,
   // so take the tiles with the least work per wave (32x32 per wave, 64-row blocks) — at P = 1 the 128-channel layers
   // of the CIFAR net run 25 blocks of 144 K-tiles otherwise (measured 177 us per launch).  A/B switch LIP_NOSMALLP.
