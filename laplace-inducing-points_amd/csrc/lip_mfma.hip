@@ -1785,6 +1785,93 @@ static hipError_t run_wgrad_skinny(const WgradP& p0, int P, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// weight gradient of the first layer (round 3): M = KH KW C <= 32 rows (27 for the CIFAR nets), 32 output columns, the
+// reduction over ALL R = n OH OW rows.  The generic kernel ran it at 18 TFLOP/s (1.25 ms per 256-probe block).  A wave
+// owns one probe and one share of the rows and sweeps it in chunks of 2 KC rows: the A operand is the TRANSPOSED
+// im2col block — lane (i = tap m, k = row parity) gathers a[pixel(row), tap m] — the B operand the cotangent rows
+// g_p[row][n] (coalesced 128-byte rows straight into the MFMA registers); KC MFMAs per chunk into one 32 x 32
+// accumulator, the next chunk's operands requested before the sweep; at the end the 27 x 32 valid entries are added
+// to Y with float atomics (one per row share).  No LDS, no barrier; bound by the read of g (R N floats per probe).
+// ------------------------------------------------------------------------------------------
+template <int KC>
+__global__ __launch_bounds__(256) void wgrad_first_kernel(const WgradP prm, int rsplit) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int M = prm.M, N = prm.N, R = prm.R;
+  const int item = (int)blockIdx.x * 4 + wave;                 // (probe, row share)
+  const int p = item / rsplit, share = item - p * rsplit;
+  if (p >= prm.P) return;
+  int rows_per = (R + rsplit - 1) / rsplit;
+  rows_per = (rows_per + 2 * KC - 1) / (2 * KC) * (2 * KC);
+  const int rbeg = share * rows_per, rend = min(R, rbeg + rows_per);
+  if (rbeg >= rend) return;
+  // this lane's tap (row m = l31 of the output): (kh, kw, c); taps >= M contribute zeros
+  const bool mv = l31 < M;
+  const int mm = mv ? l31 : 0;
+  const int tap = mm / prm.C, c = mm - tap * prm.C, kh = tap / prm.KW, kw = tap - kh * prm.KW;
+  const int th = kh - prm.pad_h, tw = kw - prm.pad_w;
+  const float* __restrict__ gp = prm.g + (long long)p * prm.g_ps;            // wave-uniform
+  const unsigned col = (unsigned)min(l31, N - 1);
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  auto load = [&](int r0, float (&a)[KC], float (&b)[KC]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      const int r = r0 + 2 * kk + lh;
+      const int rc = min(r, R - 1);
+      const int i = prm.dOHW.div(rc), rem = rc - i * prm.OHW;
+      const int oh = prm.dOW.div(rem), ow = rem - oh * prm.OW;
+      const int ih = oh * prm.stride + th, iw = ow * prm.stride + tw;
+      const bool ok = mv && r < rend && (unsigned)ih < (unsigned)prm.IH && (unsigned)iw < (unsigned)prm.IW;
+      const float t = prm.a[ok ? (unsigned)(((i * prm.IH + ih) * prm.IW + iw) * prm.C + c) : 0u];
+      a[kk] = ok ? t : 0.f;                                                  // rows past the share are zero in A: B may read any valid row
+      b[kk] = gp[(unsigned)rc * (unsigned)N + col];
+    }
+  };
+  float a0[KC], b0[KC], a1[KC], b1[KC];
+  load(rbeg, a0, b0);
+  for (int r0 = rbeg; r0 < rend; r0 += 4 * KC) {
+    if (r0 + 2 * KC < rend) load(r0 + 2 * KC, a1, b1);
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kk], b0[kk], acc, 0, 0, 0);
+    if (r0 + 2 * KC >= rend) break;
+    if (r0 + 4 * KC < rend) load(r0 + 4 * KC, a0, b0);
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc, 0, 0, 0);
+  }
+  const float sc = prm.scale ? prm.scale[col] : 1.f;
+  float* __restrict__ yb = prm.y + (long long)p * prm.y_ps;
+  if (l31 < N) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = 4 * lh + (q & 3) + 8 * (q >> 2);
+      if (m < M) atomicAdd(yb + (unsigned)(m * N + l31), acc[q] * sc);
+    }
+  }
+}
+
+static bool wgrad_first_ok(const WgradP& p, int P) {
+  static const bool off = getenv("LIP_NOFIRST") != nullptr || getenv("LIP_GENERIC") != nullptr;        // A/B switch
+  return !off && precision_mode() == 0 && p.seg_rows == 0 && p.ksplit <= 0 && p.M <= 32 && p.N <= 32 && (p.C & 3) != 0 &&
+         p.R >= 2048 && P >= 8 && (long long)p.R * p.N < (1ll << 31);
+}
+
+static hipError_t run_wgrad_first(const WgradP& p0, int P, hipStream_t st) {
+  WgradP p = p0;
+  p.P = P;
+  constexpr int KC = 32;
+  int rsplit = (2 * 4 * cu_count() + P - 1) / P;                              // ~2 waves per SIMD
+  const int maxsplit = p.R / (8 * 2 * KC) > 0 ? p.R / (8 * 2 * KC) : 1;       // >= 8 chunks per share
+  if (rsplit > maxsplit) rsplit = maxsplit;
+  if (rsplit < 1) rsplit = 1;
+  const long long items = (long long)P * rsplit;
+  hipLaunchKernelGGL((wgrad_first_kernel<KC>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p, rsplit);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // C (m, n) += A B^T for A (m, K), B (n, K) float32 with K-contiguous rows and K >> m, n (K = D ~ 1e6): the tall-skinny
 // products of the posterior engine on a materialised factor — W^T applied to a block of draws (src/sample.py:130-139),
 // the first GEMM of the factor-mode GGN-vp.  Both operands run along K in memory, i.e. both need the transposing
@@ -2385,6 +2472,7 @@ static hipError_t run_wgrad_pb(const WgradP& p, int P, hipStream_t st) {
 }
 
 hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
+  if (wgrad_first_ok(p, P)) return run_wgrad_first(p, P, st);
   if (wgrad_skinny_ok(p)) {
     if (p.R <= 16) return run_wgrad_skinny<2, 8>(p, P, st);
     if (p.R <= 52) return run_wgrad_skinny<2, 26>(p, P, st);
