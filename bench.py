@@ -531,7 +531,7 @@ def main():
         torch.cuda.synchronize()
         r50_line["inducing_gradient_step"] = dict(
             seconds=time.perf_counter() - t1, inducing_images=2, data_images=8, K=1000, d=2000, st_samples=48, slq_samples=2,
-            slq_num_matvecs=4, rank_one_directions=i50["directions"], value=v50, grad_norm=float(g50.norm().item()),
+            slq_num_matvecs=4, rank_one_directions=i50["directions"], stage_seconds=i50["stage_seconds"], value=v50, grad_norm=float(g50.norm().item()),
             grad_finite=bool(torch.isfinite(g50).all().item()), peak_memory_GiB=torch.cuda.max_memory_allocated() / 2 ** 30,
             note="value and exact gradient of alternative_objective_scalable's estimate on fixed probes (what "
                  "jax.value_and_grad returns, src/train_inducing.py:196): adjoint of Hutch++ (QR included) and of the "
@@ -643,7 +643,7 @@ def main():
         t_gs = time.perf_counter() - t1
         ipgrad_line = dict(seconds_per_step=t_g, second_order_pass_seconds=t_so, loss=loss_g,
                            stochastic=dict(seconds_per_step=t_gs, st_samples=256, slq_samples=2, slq_num_matvecs=int(n * 0.8),
-                                           rank_one_directions=info_s["directions"], value=loss_s,
+                                           rank_one_directions=info_s["directions"], stage_seconds=info_s["stage_seconds"], value=loss_s,
                                            grad_finite=bool(torch.isfinite(gZs).all().item()),
                                            cosine_to_exact_gradient=float((gZs.double() * gZ.double()).sum() /
                                                                           (gZs.double().norm() * gZ.double().norm())),

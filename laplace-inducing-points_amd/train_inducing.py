@@ -201,9 +201,19 @@ def variational_grad_stochastic(Z, X, state, alpha, key=None, model_type="classi
     sweep pairs on the inducing points' engine, one d x d Gram, and one second-order pass over the
     2 (2 s1 + s2) + 2 k slq rank-one directions.  ``example_chunk`` bounds the data images per engine binding
     (``ExampleChunkedGGN``), ``max_directions`` the directions per second-order pass."""
+    import time as _time
     from . import stochastic_grad as SG
     from .ggn import ExampleChunkedGGN
     from .second_order import EngineExecutor, input_grad_of_rank_one_terms
+    stages, _t = {}, [_time.perf_counter()]
+
+    def _mark(name):                         # stage wall times (synchronised) — only when the caller asks for them
+        if return_terms:
+            torch.cuda.synchronize()
+            now = _time.perf_counter()
+            stages[name] = now - _t[0]
+            _t[0] = now
+
     N = full_set_size or Z.shape[0]
     M = Z.shape[0]
     beta = N / M
@@ -217,7 +227,9 @@ def variational_grad_stochastic(Z, X, state, alpha, key=None, model_type="classi
     D, dev = eng.D, eng.device
     inner = WzT.out_shape
     d_z = math.prod(inner)
+    _mark("bind_engines")
     WzTWz = build_WTW(Wz, WzT, inner, d_z, dtype=torch.float64, block=1)
+    _mark("gram_WzTWz")
     if probes is None:
         probes = krylov.fill_rademacher(st_samples, D, int(key or 0), dev)        # same probes for both terms, :139-142
     st_samples = probes.shape[0]
@@ -226,10 +238,12 @@ def variational_grad_stochastic(Z, X, state, alpha, key=None, model_type="classi
     W_rows = lambda Xs: Wz.rows(Xs.to(torch.float32).reshape((Xs.shape[0],) + inner).contiguous())
     value, ld, tr, terms = SG.stochastic_objective_and_cotangent(S_rows, WT_rows, W_rows, WzTWz, D, alpha, beta, probes,
                                                                  st_samples, slq_samples, k, logdet_beta, SG.HipVec())
+    _mark("estimators_forward_and_adjoint")
     gZ = input_grad_of_rank_one_terms(EngineExecutor(eng), terms, _c_out(state, model_type), model_type, max_directions)
     gZ = gZ.reshape(Z.shape).to(Z.dtype)
+    _mark("second_order_pass")
     if return_terms:
-        return value, gZ, dict(logdet_term=ld, trace_term=tr, directions=sum(int(U.shape[0]) for U, _ in terms))
+        return value, gZ, dict(logdet_term=ld, trace_term=tr, directions=sum(int(U.shape[0]) for U, _ in terms), stage_seconds=stages)
     return value, gZ
 
 

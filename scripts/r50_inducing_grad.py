@@ -30,3 +30,4 @@ torch.cuda.synchronize()
 t1 = time.perf_counter() - t0
 print(f"M={M} Kb={Kb} st={st} k={k}: {t1:.2f} s  value {val:.6e}  directions {info['directions']}  grad finite {bool(torch.isfinite(gZ).all())} "
       f"|g| {gZ.norm().item():.3e}  peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+print("stages:", {k: round(v, 3) for k, v in info["stage_seconds"].items()})
