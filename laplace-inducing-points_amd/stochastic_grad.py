@@ -120,9 +120,9 @@ class TorchVec:
 
 
 class HipVec(TorchVec):
-    """The product backend: the D-sized operations are kernels of ``csrc/lip_krylov.hip``; the batched Gram-Schmidt
-    pieces of the SLQ adjoint (projection coefficients against / rank-one updates of a (P, j, N) block of basis
-    vectors: HBM-bound batched GEMV / GER) run as torch batched products on the device."""
+    """The product backend: the D-sized operations are kernels of ``csrc/lip_krylov.hip``, the projections of the SLQ
+    adjoint included; only its rank-one updates of a (P, j, N) block of basis cotangents (an HBM-bound batched GER) run
+    as a torch batched product on the device."""
 
     def __init__(self):
         from . import krylov
@@ -158,6 +158,19 @@ class HipVec(TorchVec):
 
     def bidiag(self, matvec, vecmat, V0, k, n_out):
         return self.k.bidiag(matvec, vecmat, V0.contiguous(), k, n_out, return_bases=True)     # (..., V, U, coefficients)
+
+    # The batched projections as library einsums fall to a generic batched-GEMM kernel once the inner dimension is the
+    # parameter count (hipBLASLt refuses k = 25.6 M: 125 ms per call, 4 s of the ResNet-50 step); per recurrence p they
+    # are exactly dot_nt (j x N against 1 x N, float64 accumulation) and rows_combine (one row out of j), which take
+    # row-strided views of the basis block as they are.
+    def proj_coeffs(self, Q, x):
+        return torch.stack([self.k.dot_nt(Q[p], x[p:p + 1])[:, 0] for p in range(Q.shape[0])]).to(x.dtype)
+
+    def sub_combination(self, x, c, Q):
+        return torch.cat([self.k.rows_combine(-c[p:p + 1].double(), Q[p], x[p:p + 1], 1.0) for p in range(Q.shape[0])])
+
+    def add_combination(self, x, c, Q):
+        return torch.cat([self.k.rows_combine(c[p:p + 1].double(), Q[p], x[p:p + 1], 1.0) for p in range(Q.shape[0])])
 
 
 # ----------------------------------------------------------------------------------------------------------------

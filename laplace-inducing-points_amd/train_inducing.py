@@ -236,6 +236,18 @@ def variational_grad_stochastic(Z, X, state, alpha, key=None, model_type="classi
     k = slq_num_matvecs if slq_num_matvecs is not None else max(1, int(M * 0.8))   # :148
     WT_rows = lambda V: WzT.rows(V.contiguous()).reshape(V.shape[0], d_z)
     W_rows = lambda Xs: Wz.rows(Xs.to(torch.float32).reshape((Xs.shape[0],) + inner).contiguous())
+    if return_terms:                         # per-operator wall time (synchronised) next to the stage times
+        def _timed(name, fn):
+            def wrapped(*a):
+                torch.cuda.synchronize()
+                t0 = _time.perf_counter()
+                out = fn(*a)
+                torch.cuda.synchronize()
+                stages["op:" + name] = stages.get("op:" + name, 0.0) + _time.perf_counter() - t0
+                stages["n:" + name] = stages.get("n:" + name, 0) + int(a[0].shape[0])
+                return out
+            return wrapped
+        S_rows, WT_rows, W_rows = _timed("S", S_rows), _timed("WzT", WT_rows), _timed("Wz", W_rows)
     value, ld, tr, terms = SG.stochastic_objective_and_cotangent(S_rows, WT_rows, W_rows, WzTWz, D, alpha, beta, probes,
                                                                  st_samples, slq_samples, k, logdet_beta, SG.HipVec())
     _mark("estimators_forward_and_adjoint")
