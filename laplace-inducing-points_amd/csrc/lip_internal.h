@@ -94,6 +94,7 @@ struct ReduceP {
   float* red1; long long red1_ps;
   // per-example rows: nseg > 0 -> grid.z = example, R rows per example, outputs at + z*red_seg
   int nseg; long long red_seg;
+  int rpb;                              // rows per block: set by launch_reduce
 };
 
 struct PoolP {

@@ -10,9 +10,10 @@ from lip_amd.toymodels import create_state
 
 if len(sys.argv) > 1 and sys.argv[1] == "resnet50":
     from lip_amd.scalemodels import ResNet50
-    P = 64
+    n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    P = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     net = ResNet50(1000); st = create_state(net, seed=1, dtype=torch.float32)
-    eng = LinearizedNet(st, torch.rand(8, 224, 224, 3).cuda(), "classifier", workspace_bytes=64 << 30, max_chunk=P)
+    eng = LinearizedNet(st, torch.rand(n_img, 224, 224, 3).cuda(), "classifier", workspace_bytes=64 << 30, max_chunk=P)
 elif len(sys.argv) > 1 and sys.argv[1] == "mlp":          # BASELINE configs[2]: MNIST-MLP 784-1024-512-256-128-10, n = 50, P = 64
     from lip_amd.scalemodels import LargeClassifier
     P = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -30,10 +31,7 @@ for which in (1, 2):
     for i, op in enumerate(eng.cn.tapes[which]):
         R = op.n_img * op.OH * op.OW
         if op.kind not in (nv.OP_IGEMM, nv.OP_WGRAD):
-            if len(sys.argv) > 1 and sys.argv[1] == "mlp":
-                fl = 0; name = f"kind {op.kind} R={R} N={op.N}"
-            else:
-                continue
+            fl = 0; name = f"kind {op.kind} R={R} N={op.N}"          # non-GEMM ops: time only
         elif op.kind == nv.OP_IGEMM:
             fl = 0; desc = []
             for q in range(op.nseg):
@@ -56,8 +54,10 @@ for which in (1, 2):
         rows.append((which, i, name, ms, fl * P / ms / 1e9))
 tot = sum(r[3] for r in rows)
 for which, i, name, ms, tf in rows:
+    if tf == 0 and ms < 0.05 and not (len(sys.argv) > 1 and sys.argv[1] == "mlp"):
+        continue
     print(f"t{which} op{i:3d} {ms:7.3f} ms {tf:6.1f} TF  {name}")
-print("total ms", tot)
+print("total ms", tot, " non-GEMM ms", sum(r[3] for r in rows if r[4] == 0))
 # whole product (fused alpha where the weight gradients allow it)
 for al in (0.0, 1e-3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
