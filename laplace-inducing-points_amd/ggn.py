@@ -241,6 +241,7 @@ def compute_W_vps(state, Z, model_type, full_set_size=None, blockwise=False):
 
     WTfun = BlockOperator(WT_block, (eng.D,), inner, eng, "WTfun")
     Wfun = BlockOperator(W_block, inner, (eng.D,), eng, "Wfun")
+    Wfun.factor_scale = WTfun.factor_scale = c          # lets build_WTW form factor columns per example (lip_vjp_rows)
     if not blockwise:
         return Wfun, WTfun
 
@@ -282,7 +283,7 @@ def _apply_block(fun, E):
     return fun.rows(E) if isinstance(fun, BlockOperator) else torch.stack([fun(e) for e in E])
 
 
-def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
+def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64, factor_bytes_limit=8 << 30):
     """``src/ggn.py:198-227``: dense W^T W (d, d), symmetrised through its upper triangle (``:227``).
 
     ``block`` only bounds peak memory in the reference (column blocks under ``jax.remat``); here it is a
@@ -294,7 +295,8 @@ def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
         dev = W.engine.device
         D = W.engine.D
         bs = max(int(block), min(d, max(1, (4 << 30) // (4 * D))))
-        if d * D * 4 <= (8 << 30):
+        c, M, K = getattr(W, "factor_scale", None), W.engine.n, W.engine.K
+        if d * D * 4 <= factor_bytes_limit:
             Wm = torch.empty(d, D, device=dev, dtype=torch.float32)
             for s in range(0, d, bs):
                 e = min(d, s + bs)
@@ -302,6 +304,20 @@ def build_WTW(W, WT, inner_shape, d, *, dtype=torch.float32, block=64):
                 E[torch.arange(e - s), torch.arange(s, e)] = 1.0
                 Wm[s:e] = W.rows(E.reshape((e - s,) + inner_shape))
             WTW = gram_from_factor(Wm)
+        elif c is not None and d == M * K and M > 1:
+            # the factor does not fit: stream column blocks, W then W^T.  Column (i, k) of W depends on example i only, so
+            # a probe holding e_k on EVERY example yields its M columns in one per-example backward sweep
+            # (lip_vjp_rows) — the summed vjp of d one-hot cotangents pushes M - 1 zero cotangents per row through the
+            # network (ResNet-50, 2 inducing images, d = 2000: 2.08 -> 1.78 s; the saving grows with M)
+            WTW = torch.empty(d, d, device=dev, dtype=torch.float32)
+            pb = max(1, bs // M)
+            eyeK = torch.eye(K, device=dev, dtype=torch.float32)
+            for k0 in range(0, K, pb):
+                k1 = min(K, k0 + pb)
+                U = eyeK[k0:k1, None, :].expand(k1 - k0, M, K).contiguous()
+                cols = W.engine.vjp_rows(U, "l", c).reshape((k1 - k0) * M, D)           # row (j, i) = column (i, k0 + j) of W
+                G = WT.rows(cols).reshape(k1 - k0, M, d)
+                WTW.view(d, M, K)[:, :, k0:k1] = G.permute(2, 1, 0)
         else:
             WTW = torch.empty(d, d, device=dev, dtype=torch.float32)
             for s in range(0, d, bs):

@@ -50,6 +50,32 @@ def test_WT_W_vps_2(impl, classification_2d_data, classifier_state):
     assert torch.allclose(cpu64(WTW), cpu64(WTW).T)
 
 
+@pytest.mark.gpu
+def test_build_WTW_streamed_routes_agree(classification_2d_data, classifier_state):
+    """build_WTW (src/ggn.py:198-227) has three routes on the engine: the materialised factor, column blocks streamed
+    through per-example backward sweeps (what a factor too large for HBM takes: ResNet-50, K = 1000) and column blocks
+    of one-hot cotangents through the summed vjp.  Same Gram from all three, and equal to the oracle's."""
+    from impl import _Hip
+    impl = _Hip()
+    X, _ = classification_2d_data
+    X = X[::8]
+    st, Xd = impl.state(classifier_state), impl.tensor(X)
+    W, WT = impl.ggn.compute_W_vps(st, Xd, "classifier", full_set_size=77)
+    inner = WT.out_shape
+    d = int(torch.tensor(inner).prod())
+    G_fac = impl.ggn.build_WTW(W, WT, inner, d, dtype=torch.float64, block=1)
+    G_rows = impl.ggn.build_WTW(W, WT, inner, d, dtype=torch.float64, block=3, factor_bytes_limit=0)
+    scale = W.factor_scale
+    del W.factor_scale                                    # without the scale: the one-hot route
+    G_hot = impl.ggn.build_WTW(W, WT, inner, d, dtype=torch.float64, block=3, factor_bytes_limit=0)
+    W.factor_scale = scale
+    Wo, WTo = og.compute_W_vps(classifier_state, X, "classifier", full_set_size=77)
+    ref = og.build_WTW(Wo, WTo, inner, d, dtype=torch.float64)
+    tol = 2e-5 * float(ref.abs().max())
+    for G in (G_fac, G_rows, G_hot):
+        assert float((cpu64(G) - ref).abs().max()) < tol
+
+
 def test_nullproj(impl, sine_data, toyregressor_state):
     """reference :110-152: v - W (W^T W)^-1 W^T v lies in the kernel of the GGN (CG inverse, atol 1.5e-3)."""
     X, y = sine_data
