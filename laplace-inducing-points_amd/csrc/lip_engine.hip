@@ -481,13 +481,20 @@ int lip_debug_run_ops(lip_engine_t* e, int32_t which, int32_t first, int32_t cou
   return LIP_OK;
 }
 
+// Probes per pass when P exceeds the workspace: equal passes (256 probes on an 85-probe workspace run 4 x 64, not
+// 85 + 85 + 85 + 1 — a one-probe pass costs 2 ms of under-filled launches, a quarter of a 64-probe pass)
+static inline int balanced_chunk(int P, int max_chunk) {
+  const int passes = (P + max_chunk - 1) / max_chunk;
+  return (P + passes - 1) / passes;
+}
+
 int lip_ggn_vp(lip_engine_t* e, const float* V, float* Y, int32_t P, float scale, float alpha, void* stream) {
   int rc = ready(e, "lip_ggn_vp");
   if (rc) return rc;
   if (!V || !Y || P <= 0) { set_error("lip_ggn_vp: bad argument"); return LIP_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
-    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+  for (int c0 = 0, step = balanced_chunk(P, e->max_chunk); c0 < P; c0 += step) {
+    const int pc = (P - c0) < step ? (P - c0) : step;
     const float* v = V + (int64_t)c0 * e->D;
     float* y = Y + (int64_t)c0 * e->D;
     RunCtx c{e, v, y, nullptr, pc, LIP_HEAD_GGN, scale, st};
@@ -504,8 +511,8 @@ int lip_jvp(lip_engine_t* e, const float* V, float* U, int32_t P, int32_t head_m
   if (rc) return rc;
   if (!V || !U || P <= 0 || (head_mode != LIP_HEAD_LT && head_mode != LIP_HEAD_OUT)) { set_error("lip_jvp: bad argument"); return LIP_ERR_ARG; }
   const int64_t hstride = (int64_t)e->n_img * e->K;
-  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
-    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+  for (int c0 = 0, step = balanced_chunk(P, e->max_chunk); c0 < P; c0 += step) {
+    const int pc = (P - c0) < step ? (P - c0) : step;
     RunCtx c{e, V + (int64_t)c0 * e->D, nullptr, U + (int64_t)c0 * hstride, pc, head_mode, cc, (hipStream_t)stream};
     if ((rc = run_tape(c, LIP_TAPE_TANGENT, false))) return rc;
   }
@@ -518,8 +525,8 @@ int lip_vjp(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t head_m
   if (!U || !Y || P <= 0 || (head_mode != LIP_HEAD_L && head_mode != LIP_HEAD_IN)) { set_error("lip_vjp: bad argument"); return LIP_ERR_ARG; }
   const int64_t hstride = (int64_t)e->n_img * e->K;
   hipStream_t st = (hipStream_t)stream;
-  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
-    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+  for (int c0 = 0, step = balanced_chunk(P, e->max_chunk); c0 < P; c0 += step) {
+    const int pc = (P - c0) < step ? (P - c0) : step;
     float* y = Y + (int64_t)c0 * e->D;
     RunCtx c{e, nullptr, y, const_cast<float*>(U) + (int64_t)c0 * hstride, pc, head_mode, cc, st};
     c.fuse = true; c.alpha = 0.f;
@@ -535,8 +542,8 @@ int lip_vjp_rows(lip_engine_t* e, const float* U, float* Y, int32_t P, int32_t h
   if (!U || !Y || P <= 0 || (head_mode != LIP_HEAD_L && head_mode != LIP_HEAD_IN)) { set_error("lip_vjp_rows: bad argument"); return LIP_ERR_ARG; }
   const int64_t hstride = (int64_t)e->n_img * e->K, ystride = (int64_t)e->n_img * e->D;
   hipStream_t st = (hipStream_t)stream;
-  for (int c0 = 0; c0 < P; c0 += e->max_chunk) {
-    const int pc = (P - c0) < e->max_chunk ? (P - c0) : e->max_chunk;
+  for (int c0 = 0, step = balanced_chunk(P, e->max_chunk); c0 < P; c0 += step) {
+    const int pc = (P - c0) < step ? (P - c0) : step;
     float* y = Y + (int64_t)c0 * ystride;
     RUN_CHECK(hipMemsetAsync(y, 0, sizeof(float) * (size_t)pc * ystride, st), "memset Y");
     RunCtx c{e, nullptr, y, const_cast<float*>(U) + (int64_t)c0 * hstride, pc, head_mode, cc, st, true};

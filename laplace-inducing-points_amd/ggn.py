@@ -44,14 +44,47 @@ def engine_key(state, Z, model_type):
 _EVICTION_HOOKS = []          # callables(key) run when a binding leaves the cache (the sampler drops its parts)
 
 
-def get_engine(state, Z, model_type, workspace_bytes: int = 8 << 30) -> LinearizedNet:
+_SHARED_WORK = {}
+
+
+def shared_workspace(device) -> torch.Tensor:
+    """ONE probe workspace per device for the cached engines: the workspace is scratch inside a call and the calls of a
+    process run one after the other on one stream, so the bindings need not own one each (four cached engines x 8 GB
+    before, and 8 GB held the CIFAR net to 85 probes per pass — the 256-probe blocks of the Krylov loops ran as
+    85 + 85 + 85 + 1).  An eighth of the card's memory, at most 32 GB (340 probes of the CIFAR config per pass);
+    ``LIP_WORKSPACE_GB`` overrides."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    w = _SHARED_WORK.get(idx)
+    if w is None:
+        import os
+        gb = os.environ.get("LIP_WORKSPACE_GB")
+        total = torch.cuda.get_device_properties(idx).total_memory
+        nbytes = int(float(gb) * (1 << 30)) if gb else min(32 << 30, total // 8)
+        w = torch.empty(nbytes // 4, device=torch.device("cuda", idx), dtype=torch.float32)
+        _SHARED_WORK[idx] = w
+    return w
+
+
+def get_engine(state, Z, model_type, workspace_bytes: Optional[int] = None) -> LinearizedNet:
     """One engine per (theta snapshot, Z snapshot, model_type).  The cache is LRU: a hit moves the binding to the
     fresh end, so the inducing-point engine an evaluation loop returns to every batch survives the per-batch
-    prediction engines that pass through (``scale_experiments/evaluate.py:98-154``)."""
+    prediction engines that pass through (``scale_experiments/evaluate.py:98-154``).  The bindings share one probe
+    workspace (:func:`shared_workspace`) unless ``workspace_bytes`` asks for a private one."""
     key = engine_key(state, Z, model_type)
     eng = _ENGINE_CACHE.pop(key, None)
     if eng is None:
-        eng = LinearizedNet(state, Z, model_type, workspace_bytes=workspace_bytes)
+        if workspace_bytes is None:
+            dev = torch.device("cuda")
+            work = shared_workspace(dev)
+            try:
+                eng = LinearizedNet(state, Z, model_type, work=work)
+            except ValueError as err:
+                if "shared workspace" not in str(err):
+                    raise
+                eng = LinearizedNet(state, Z, model_type)     # one probe does not fit the pool: a private workspace
+        else:
+            eng = LinearizedNet(state, Z, model_type, workspace_bytes=workspace_bytes)
         eng._keepalive = (state.params, state.batch_stats, Z)   # keep the keyed storage alive
         eng.cache_key = key
         while len(_ENGINE_CACHE) >= _ENGINE_CACHE_MAX:

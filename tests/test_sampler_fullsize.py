@@ -151,19 +151,22 @@ def test_deflated_cg_solves_the_config_system(setup):
     with range(W) deflated the complement solve converges in a couple of iterations.  Reference: the closed form in the
     invariant subspaces (``RangeDeflation.closed_form``); asserted is the FORWARD error — a float32-stored x cannot
     make the residual small at this conditioning (eps * cond = 180; the residual evaluated subspace-wise is printed).
-    Stopping tolerance 1e-3: the floor of the deflated float32 product (the deflated Lanczos draws show the same
-    8e-4 .. 1.6e-3), below which a float32 CG only accumulates rounding (tol 1e-6: 50 iterations, error O(1))."""
+    Stopping tolerance 3e-3: three times the floor of the deflated float32 product (the deflated Lanczos draws show
+    8e-4 .. 1.6e-3).  AT the floor (tol 1e-3) the recurrence is decided by rounding that differs between runs (the
+    weight-gradient kernels add their row splits with float atomics): 2 - 8 iterations and forward errors from 5e-3 to
+    1.7e-1 were seen on identical inputs (``scripts/cg_floor_probe.py``); below it a float32 CG only accumulates rounding
+    (tol 1e-6: 50 iterations, error O(1)).  At 3e-3: 2 iterations, 5e-4 .. 4.4e-3 over eight runs."""
     from lip_amd import krylov
     from lip_amd.sample import range_deflation
     s = setup
     B = s["V"][:8].contiguous()
     defl = range_deflation(s["st"], s["Z"], s["eng"].D, ALPHA, "classifier", FULL)
     Xref = defl.closed_form(B, lambda lam: 1.0 / lam, ALPHA)
-    X, info = krylov.cg_deflated(s["A"], B, defl, tol=1e-3, maxiter=50, stall=3)
+    X, info = krylov.cg_deflated(s["A"], B, defl, tol=3e-3, maxiter=50, stall=3)
     err = ((X - Xref).norm(dim=1) / Xref.norm(dim=1)).max().item()
     res = defl.relative_residual(s["A"], X, B).max().item()
-    Xp, infop = krylov.cg(s["A"], B, tol=1e-3, maxiter=50)
+    Xp, infop = krylov.cg(s["A"], B, tol=3e-3, maxiter=50)
     errp = ((Xp - Xref).norm(dim=1) / Xref.norm(dim=1)).max().item()
     print(f"SAMPLER_FULLSIZE cg alpha={ALPHA}: deflated {info['iterations']} iterations forward error {err:.3e} (subspace residual "
           f"{res:.3e}); plain {infop['iterations']} iterations forward error {errp:.3e}")
-    assert info["iterations"] <= 8 and err <= 2e-2 and errp > 0.5          # measured 5 iterations, 8e-3; plain 0.74
+    assert info["iterations"] <= 4 and err <= 1.5e-2 and errp > 0.5        # measured 2 iterations, <= 4.4e-3; plain 0.74
