@@ -310,7 +310,8 @@ def funm_lanczos_dense(dense_funm: Callable, num_matvecs: int):
 
 
 def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[torch.Tensor] = None, tol: float = 1e-5,
-       atol: float = 0.0, maxiter: Optional[int] = None, check_every: int = 1, stall: Optional[int] = None):
+       atol: float = 0.0, maxiter: Optional[int] = None, check_every: int = 1, stall: Optional[int] = None,
+       keep_best: bool = False):
     """Batched conjugate gradients, one independent solve per row of B (P, N), with JAX's defaults and
     stopping rule (||r||^2 <= max(tol^2 ||b||^2, atol^2), maxiter = 10 N).  Returns ``(X, info)`` where
     info holds the iteration count and final residual norms (the reference discards it).
@@ -318,7 +319,14 @@ def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[
     ``stall`` (not in JAX): a right-hand side whose recurrence residual has not dropped by 10 % below its best value for
     ``stall`` consecutive iterations is frozen — a float32 recurrence that has reached the noise floor of its operator
     only accumulates rounding when iterated further (forward error 8e-3 after 5 steps, 8e-2 after 200 at the CIFAR
-    config's alpha = 0.005, deflated operator)."""
+    config's alpha = 0.005, deflated operator).
+
+    ``keep_best`` (not in JAX): after every step the TRUE residual b - A x is evaluated (one more product per iteration)
+    and, per right-hand side, the iterate with the smallest one is what is returned; a right-hand side stops when its
+    true residual meets the tolerance or has not improved for ``stall`` (default 2) steps.  For operators whose float32
+    product carries noise of the size of the tolerance: the recurrence residual then says nothing about x, and a step
+    taken along a noise-dominated direction can throw the iterate far off (seen: forward error 2e-1 after 4 steps where
+    the first iterate was at 1e-3)."""
     lib = nv.load()
     B = _chk(B.contiguous())
     P, N = B.shape
@@ -334,6 +342,30 @@ def cg(A: Callable[[torch.Tensor], torch.Tensor], B: torch.Tensor, x0: Optional[
     rr_new = torch.empty_like(rr)
     best, since = rr.clone(), torch.zeros_like(active)
     it = 0
+    if keep_best:
+        patience = 2 if stall is None else int(stall)
+        Xb = X.clone()
+        tb = bdot(R, R)                                  # true residual of the iterate kept (x0: r = b - A x0)
+        alive = (tb > atol2)
+        idle = torch.zeros_like(active)
+        while it < maxiter and bool(alive.any()):
+            act32 = alive.to(torch.int32)
+            Ap = _chk(A(Pd).contiguous())
+            pAp = bdot(Pd, Ap)
+            nv.check(lib.lip_cg_update(nv.ptr(X), nv.ptr(R), nv.ptr(Pd), nv.ptr(Ap), nv.ptr(rr), nv.ptr(pAp), nv.ptr(act32),
+                                       nv.ptr(rr_new), P, N, st), "lip_cg_update")
+            nv.check(lib.lip_cg_direction(nv.ptr(Pd), nv.ptr(R), nv.ptr(rr_new), nv.ptr(rr), nv.ptr(act32), P, N, st),
+                     "lip_cg_direction")
+            rr = torch.where(alive, rr_new, rr)
+            Rt = (B - _chk(A(X).contiguous()))
+            tt = bdot(Rt, Rt)
+            better = alive & (tt < tb)
+            Xb = torch.where(better[:, None], X, Xb)
+            idle = torch.where(tt < 0.81 * tb, torch.zeros_like(idle), idle + 1)
+            tb = torch.where(better, tt, tb)
+            alive = alive & (tb > atol2) & (idle < patience)
+            it += 1
+        return Xb, dict(iterations=it, residual_norm=torch.sqrt(tb))
     while it < maxiter:
         if it % check_every == 0 and not bool(active.any()):
             break
@@ -510,9 +542,11 @@ class RangeDeflation:
 
 def cg_deflated(A: Callable, B: torch.Tensor, defl: RangeDeflation, **cg_kw):
     """A^-1 B with the invariant subspace of ``defl`` solved exactly and CG run on the complement (:func:`cg`'s
-    arguments and return value; the iteration count is that of the complement solve)."""
+    arguments and return value; the iteration count is that of the complement solve; ``keep_best`` defaults to True:
+    the iterate with the smallest true residual on the complement is returned)."""
     B = _chk(B.contiguous())
     C = defl.coeffs(B)
+    cg_kw.setdefault("keep_best", True)             # the complement's product is noise-limited: see :func:`cg`
     Xp, info = cg(defl.wrap(A), defl.project_out(B, C), **cg_kw)
     Xp = defl.project_out(Xp)                       # what the recurrence let leak back into range(Q)
     X = axpby(defl.range_part(C, lambda lam: 1.0 / lam), Xp, None, 1.0, None, 1.0)

@@ -137,6 +137,43 @@ def test_probe_chunking_and_single_vector():
     assert torch.allclose(a[2], c[0], rtol=1e-4, atol=1e-5)   # split-K atomics reorder the sum
 
 
+@pytest.mark.parametrize("name", ["resnet1m", "mlp_ragged"])
+def test_products_do_not_read_stale_workspace(name):
+    """The cached bindings share ONE probe workspace (``ggn.shared_workspace``), so whatever another engine left there must
+    not matter: every product is run with the workspace filled with NaN and with 1e30 beforehand and compared with the run
+    on a zeroed workspace — a kernel that reads an element its own call has not written would return NaN / garbage."""
+    if name == "resnet1m":
+        net, model_type = ResNet1M(10), "classifier"
+        Z = torch.rand(6, 32, 32, 3, generator=torch.Generator().manual_seed(2))
+    else:
+        net, Z, model_type, _ = _cases()[name]
+    state = create_state(net, 4, dtype=F64)
+    work = torch.empty(1 << 28, device="cuda", dtype=torch.float32)                 # 1 GiB shared pool
+    eng = LinearizedNet(state, Z, model_type, work=work)
+    other = LinearizedNet(create_state(SimpleClassifier(6, 2, 3), 1, dtype=F64), torch.randn(5, 2), "classifier", work=work)
+    g = torch.Generator().manual_seed(9)
+    for P in (1, 5, 17):
+        V = torch.randn(P, eng.D, generator=g).cuda()
+        U = torch.randn(P, eng.n, eng.K, generator=g).cuda()
+        calls = (lambda: eng.ggn_vp(V, 3.0, 0.01), lambda: eng.jvp(V, "lt", 1.0), lambda: eng.vjp(U, "l", 1.0),
+                 lambda: eng.vjp_rows(U[:2].contiguous(), "l", 1.0))
+        ref = None
+        for fill in (0.0, float("nan"), 1e30, "other engine"):
+            outs = []
+            for fn in calls:
+                if fill == "other engine":
+                    other.ggn_vp(torch.randn(4, other.D).cuda(), 1.0, 0.0)
+                else:
+                    work.fill_(fill)
+                outs.append(fn().double())
+            if ref is None:
+                ref = outs
+                continue
+            for o, r in zip(outs, ref):
+                assert bool(torch.isfinite(o).all()), f"{name} P={P}: workspace content {fill} reached the output"
+                assert float((o - r).abs().max()) <= 2e-6 * float(r.abs().max()), (name, P, fill)     # float atomics reorder sums
+
+
 def test_factor_rows_per_example_equal_one_hot_sweeps():
     """materialize_factor: K probes through the per-example sweep == d one-hot cotangents through the summed vjp."""
     from lip_amd.ggn import materialize_factor

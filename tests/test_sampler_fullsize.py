@@ -155,7 +155,9 @@ def test_deflated_cg_solves_the_config_system(setup):
     8e-4 .. 1.6e-3).  AT the floor (tol 1e-3) the recurrence is decided by rounding that differs between runs (the
     weight-gradient kernels add their row splits with float atomics): 2 - 8 iterations and forward errors from 5e-3 to
     1.7e-1 were seen on identical inputs (``scripts/cg_floor_probe.py``); below it a float32 CG only accumulates rounding
-    (tol 1e-6: 50 iterations, error O(1)).  At 3e-3: 2 iterations, 5e-4 .. 4.4e-3 over eight runs."""
+    (tol 1e-6: 50 iterations, error O(1)).  At 3e-3: 2 iterations, 5e-4 .. 4.4e-3 over eight runs in a fresh process —
+    and 2e-1 after 4 steps inside the full test session (other kernel paths, other rounding): ``cg_deflated`` therefore
+    evaluates the true residual on the complement every step and returns the best iterate (``cg(keep_best=True)``)."""
     from lip_amd import krylov
     from lip_amd.sample import range_deflation
     s = setup
