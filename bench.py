@@ -477,15 +477,16 @@ def main():
                              "(1024 probes x 10k images over 8 GPUs = 160 such blocks x 16 probe chunks per GPU)")
         del e50, V50, Y50
         torch.cuda.empty_cache()
-        # the data sum over MANY images: 256 images as 32 chunks of 8 behind one shared probe workspace
-        # (ExampleChunkedGGN — the single-GPU twin of the 8-GPU shard of configs[4]), 16 probes
+        # the data sum over MANY images: 256 images as 8 chunks of 32 behind one shared probe workspace
+        # (ExampleChunkedGGN — the single-GPU twin of the 8-GPU shard of configs[4]), 16 probes.  (32 chunks of 8 images
+        # until late in round 3: 84 TFLOP/s — 16 probes over 8 images leave the deep layers 392 rows per launch.)
         from lip_amd.ggn import ExampleChunkedGGN
         n256, P256 = 256, 16
         Z256 = torch.rand(n256, 224, 224, 3, generator=torch.Generator().manual_seed(4)).to(dev)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ch = ExampleChunkedGGN(st50.to(device=dev, dtype=torch.float32), Z256, "classifier", full_set_size=10000,
-                               example_chunk=8, workspace_bytes=24 << 30, max_probes=P256)
+                               example_chunk=32, workspace_bytes=72 << 30, max_probes=P256)
         torch.cuda.synchronize()
         t_bind = time.perf_counter() - t1
         V256 = krylov.fill_rademacher(P256, ch.D, 12, dev)

@@ -2495,7 +2495,9 @@ hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
       return (precision_mode() == 1 || w3) ? run_wgrad_pb<3, 1, 1, 4>(p, P, st) : run_wgrad_pb<1, 4, 3, 1>(p, P, st);
     return run_wgrad_pb<2, 2, 2, 2>(p, P, st);
   }
-  // (64-row per-probe tiles for M = 288 were measured slower than 128-row ones: 54.6 vs 52.4 ms per step — removed)
+  // (64-row per-probe tiles for M = 288 were measured slower than 128-row ones: 54.6 vs 52.4 ms per step — removed;
+  //  a 96 x 256 probe-batched tile <1,4,3,2> — the transposed im2col gather shared by eight probes instead of four — ran
+  //  the M = 288 / 576 launches at 105 instead of 113 TFLOP/s: removed)
   const bool small_m = p.M <= 64;
   if (p.N > 64) return small_m ? run_wgrad<2, 2, 1, 2>(p, P, st) : run_wgrad<2, 2, 2, 2>(p, P, st);
   if (p.N > 32) return small_m ? run_wgrad<2, 2, 1, 1>(p, P, st) : run_wgrad<4, 1, 1, 2>(p, P, st);

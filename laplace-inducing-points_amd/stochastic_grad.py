@@ -44,7 +44,7 @@ tests of the host logic against reverse mode through the oracle).
 from __future__ import annotations
 
 import math
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Tuple
 
 import torch
 
