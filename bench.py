@@ -696,7 +696,15 @@ def main():
             note="BASELINE configs[2] (synthetic 28x28 inputs: the MNIST blob is absent): 64 Rademacher probes, one block "
                  "product, 64 dots; per probe the sweep reads its D tangent weights and writes its D cotangents, so this "
                  "small net is HBM-bound: bytes = 4 passes over the (64, D) block")
-        del em, op_m, Zm
+        # the same estimate from the operator's quadratic forms (what compute_ggn_vp / compute_curvature_approx hand to the
+        # estimators: eps^T GGN eps = sum_i ||L_i^T J_i eps||^2 — the tangent sweep alone, no (P, D) output block)
+        from lip_amd.ggn import attach_quadratic_forms
+        op_mq = attach_quadratic_forms(BlockOperator(op_m.rows, (em.D,), (em.D,), em, "mnist"), em, 1.0, 1e-3)
+        t_mq, tr_mq = timed(lambda: stochtrace.stochastic_trace_estimator_mvp(op_mq, em.D, 11, num_samples=64, device=dev))
+        trace_line["hutchinson_mnist_mlp_64"]["quadratic_forms"] = dict(
+            seconds=t_mq, trace=tr_mq, rel_diff=abs(tr_mq - tr_m) / abs(tr_m), algorithmic_GBps=2.0 * em.D * 64 * 4 / t_mq / 1e9,
+            note="tangent sweep + K-vector head only (lip_jvp, LIP_HEAD_LT): bytes = write eps, read eps")
+        del em, op_m, op_mq, Zm
         # configs[3]: Hutch++ (s1 = 20, s2 = 16 as src/train_inducing.py:139-146 at st_samples = 36) on the CIFAR
         # binding of the headline: 2 s1 + s2 = 56 products as three blocks + the tall-skinny orthonormalisation
         op_c = BlockOperator(lambda B: eng.ggn_vp(B, scale, alpha), (eng.D,), (eng.D,), eng, "cifar")
@@ -718,8 +726,16 @@ def main():
                  "bytes 2 x 12 D s (SURVEY 8d: >= 12 D s per pass); Hutchinson with 256 probes on the same binding is the "
                  "headline step plus 256 dots")
         t_256, tr_256 = timed(lambda: stochtrace.stochastic_trace_estimator_mvp(op_c, eng.D, 13, num_samples=256, device=dev), reps=2)
+        op_cq = attach_quadratic_forms(BlockOperator(op_c.rows, (eng.D,), (eng.D,), eng, "cifar"), eng, scale, alpha)
+        t_256q, tr_256q = timed(lambda: stochtrace.stochastic_trace_estimator_mvp(op_cq, eng.D, 13, num_samples=256, device=dev), reps=2)
+        t_hq, tr_hq = timed(lambda: stochtrace.hutchpp_v2(op_cq, lambda _: probes36, s1=20, s2=16))
         trace_line["hutchinson_cifar_256"] = dict(seconds=t_256, trace=tr_256, probes=256,
-                                                  note="fill 256 Rademacher probes + one block product + 256 dots")
+                                                  note="fill 256 Rademacher probes + one block product + 256 dots",
+                                                  quadratic_forms=dict(seconds=t_256q, trace=tr_256q, rel_diff=abs(tr_256q - tr_256) / abs(tr_256),
+                                                                       note="fill + one tangent sweep + 256 squared norms in output space"))
+        trace_line["hutchpp_v2_cifar_s1_20_s2_16"]["quadratic_forms"] = dict(
+            seconds=t_hq, trace=tr_hq, rel_diff=abs(tr_hq - tr_h) / abs(tr_h),
+            note="20 products for the sketch, the two quadratic forms (20 + 16 rows) from tangent sweeps")
 
     krylov_line = None
     if args.samples > 0 and rank == 0 and world == 1:

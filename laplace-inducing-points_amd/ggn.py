@@ -125,6 +125,27 @@ class BlockOperator:
         return self._fn(Mcols.T.contiguous()).T
 
 
+def attach_quadratic_forms(op: "BlockOperator", eng, scale: float, alpha: float = 0.0) -> "BlockOperator":
+    """``op.quadratic_forms(V) -> (P,) float64``: v^T (scale GGN + alpha I) v for every row of V WITHOUT the backward sweep:
+    GGN = sum_i J_i^T L_i L_i^T J_i (``src/ggn.py:16-39``), so v^T GGN v = sum_i ||L_i^T J_i v||^2 — one tangent-forward
+    sweep and the K-vector head (``lip_jvp``, ``LIP_HEAD_LT``), half the arithmetic of the product and no (P, D) output block.
+    The estimators that only need eps^T X eps (Hutchinson ``src/stochtrace.py:30-34``, the two quadratic forms of Hutch++
+    ``:75,109-111,133-134``) use it when the operator offers it; every other operator goes through its products."""
+    from . import krylov
+    c = math.sqrt(scale)
+
+    def quadratic_forms(V):
+        Vb = V.to(device=eng.device, dtype=torch.float32).contiguous()
+        U = eng.jvp(Vb, "lt", c).double().reshape(Vb.shape[0], -1)
+        q = (U * U).sum(1)
+        if alpha != 0.0:
+            q = q + float(alpha) * krylov.bdot(Vb, Vb).double()
+        return q
+
+    op.quadratic_forms = quadratic_forms
+    return op
+
+
 def _logvar(state):
     return float(torch.as_tensor(state.params["logvar"]["logvar"]).detach().cpu())
 
@@ -234,7 +255,8 @@ def compute_ggn_vp(state, Z, model_type, full_set_size=None, mode: str = "matfre
     if mode == "auto":
         mode = "factor" if eng.n * eng.K * eng.D * 4 <= FACTOR_BYTES_LIMIT else "matfree"
     if mode == "matfree":
-        return BlockOperator(lambda V: eng.ggn_vp(V, recal_term, 0.0), (eng.D,), (eng.D,), eng, "ggn_vp")
+        return attach_quadratic_forms(BlockOperator(lambda V: eng.ggn_vp(V, recal_term, 0.0), (eng.D,), (eng.D,), eng, "ggn_vp"),
+                                      eng, recal_term)
     if mode != "factor":
         raise ValueError("mode must be 'matfree', 'factor' or 'auto'")
     Wm = materialize_factor(eng, math.sqrt(recal_term))

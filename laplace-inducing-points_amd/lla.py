@@ -26,7 +26,9 @@ def compute_curvature_approx(map_state, Z, model_type, alpha, full_set_size=None
     M = Z.shape[0]
     N = full_set_size or M
     scale = N / M * (math.exp(-float(map_state.params["logvar"]["logvar"])) if model_type == "regressor" else 1.0)
-    return BlockOperator(lambda V: eng.ggn_vp(V, scale, float(alpha)), (eng.D,), (eng.D,), eng, "curvature_vp")
+    from .ggn import attach_quadratic_forms
+    return attach_quadratic_forms(BlockOperator(lambda V: eng.ggn_vp(V, scale, float(alpha)), (eng.D,), (eng.D,), eng, "curvature_vp"),
+                                  eng, scale, float(alpha))
 
 
 def compute_curvature_approx_dense(map_state, x, model_type, alpha, full_set_size=None):

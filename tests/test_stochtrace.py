@@ -115,3 +115,33 @@ def test_inv_na_hutchpp(impl, suites):
     fA = _fun(impl, A) if impl.is_hip else (lambda V: A @ V)
     tr = st.na_hutchpp_inv_mvp(fA, n, 2894598, num_samples=60)
     assert torch.isclose(cpu64(tr), torch.trace(torch.linalg.inv(cpu64(A))), rtol=5e-2)
+
+
+@pytest.mark.gpu
+def test_quadratic_forms_of_the_ggn_operators_equal_their_products():
+    """v^T (GGN + alpha I) v through the tangent sweep alone (``attach_quadratic_forms``: sum_i ||L_i^T J_i v||^2 + alpha ||v||^2)
+    against <v, X v> from the block product, classifier and regressor; and the trace estimators give the same number
+    with and without the shortcut (the same operator stripped of it)."""
+    from lip_amd import krylov, stochtrace
+    from lip_amd.ggn import BlockOperator, compute_ggn_vp
+    from lip_amd.lla import compute_curvature_approx
+    from lip_amd.toymodels import SimpleClassifier, SimpleRegressor, create_state
+    g = torch.Generator().manual_seed(3)
+    for net, Z, mt in ((SimpleClassifier(16, 2, 3), torch.randn(9, 2, generator=g), "classifier"),
+                       (SimpleRegressor(12, 2), torch.randn(7, 1, generator=g), "regressor")):
+        st = create_state(net, 7, dtype=torch.float32, **({"logvar": -0.7} if mt == "regressor" else {})).to(device="cuda", dtype=torch.float32)
+        Zd = Z.cuda()
+        for op in (compute_ggn_vp(st, Zd, mt, full_set_size=40), compute_curvature_approx(st, Zd, mt, alpha=0.37, full_set_size=40)):
+            D = op.engine.D
+            V = krylov.fill_normal(11, D, 5, "cuda")
+            q = op.quadratic_forms(V)
+            ref = (V.double() * op.rows(V).double()).sum(1)
+            assert float((q - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+            plain = BlockOperator(op.rows, (D,), (D,), op.engine, "no shortcut")
+            sampler = lambda *_: krylov.fill_normal(24, D, 9, "cuda")
+            for est in (lambda X: stochtrace.stochastic_trace_estimator_mvp(X, D, 4, num_samples=32),
+                        lambda X: stochtrace.hutchpp_mvp(X, D, 4, num_samples=6),
+                        lambda X: stochtrace.hutchpp(X, sampler),
+                        lambda X: stochtrace.hutchpp_v2(X, sampler, s1=8, s2=16)):
+                a, b = float(est(op)), float(est(plain))
+                assert abs(a - b) <= 1e-4 * abs(b), (mt, a, b)
