@@ -123,6 +123,13 @@ int lip_get_precision(void);
  * results differ only in the summation order of the K axis; the switch exists so that a test can compare the two
  * orders in one process (the environment variable LIP_NOKSPLIT is read once).                          */
 int lip_set_split_k(int32_t on);
+/* Winograd F(2x2, 3x3) route of the 3x3 / stride-1 / pad-1 layers of the tangent and backward tapes (2.25x fewer
+ * matrix-pipe multiplications, f32 in / f32 accumulate; the transforms move a layer's result by ~2e-7 relative;
+ * DESIGN.md section 4): 0 = off (the direct implicit GEMMs everywhere), 1 = auto (default: launches that fill the
+ * chip), 2 = every eligible launch (tests).  Never applied to the primal tape.  The environment variables
+ * LIP_NOWINO / LIP_WINO=force are read once; this call overrides them.                                  */
+int lip_set_winograd(int32_t mode);
+int lip_get_winograd(void);
 
 /* ---- engine: one per (network, theta_MAP, data slice Z) binding on one device --------
  * Replaces the closure factories compute_ggn_vp / compute_W_vps (src/ggn.py:97,9): they

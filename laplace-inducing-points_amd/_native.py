@@ -57,6 +57,8 @@ SIGNATURES = {
     "lip_sizeof_op": (C.c_int, []),
     "lip_set_precision": (C.c_int, [C.c_int32]),
     "lip_set_split_k": (C.c_int, [C.c_int32]),
+    "lip_set_winograd": (C.c_int, [C.c_int32]),
+    "lip_get_winograd": (C.c_int, []),
     "lip_get_precision": (C.c_int, []),
     "lip_engine_create": (C.c_int, [C.POINTER(_V), C.c_int64, C.c_int32, C.c_int32]),
     "lip_engine_destroy": (C.c_int, [_V]),

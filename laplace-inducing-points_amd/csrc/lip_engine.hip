@@ -383,11 +383,13 @@ int ready(const lip_engine* e, const char* who) {
 
 extern "C" {
 
-int lip_abi_version(void) { return 7; }
+int lip_abi_version(void) { return 8; }
 const char* lip_last_error(void) { return g_err; }
 int lip_sizeof_op(void) { return (int)sizeof(lip_op_t); }
 int lip_set_precision(int32_t mode) { if (mode != 0 && mode != 1) { set_error("lip_set_precision: mode must be 0 (f32) or 1 (bf16x3)"); return LIP_ERR_ARG; } set_precision_mode(mode); return LIP_OK; }
 int lip_set_split_k(int32_t on) { set_split_k_mode(on != 0); return LIP_OK; }
+int lip_set_winograd(int32_t mode) { if (mode < 0 || mode > 2) { set_error("lip_set_winograd: mode must be 0 (off), 1 (auto) or 2 (every eligible launch)"); return LIP_ERR_ARG; } set_wino_mode(mode); return LIP_OK; }
+int lip_get_winograd(void) { return wino_mode(); }
 int lip_get_precision(void) { return precision_mode(); }
 
 int lip_engine_create(lip_engine_t** out, int64_t D, int32_t n_img, int32_t K) {

@@ -160,6 +160,8 @@ void set_error(const char* fmt, ...);
 int precision_mode();
 void set_precision_mode(int m);
 void set_split_k_mode(int on);
+void set_wino_mode(int m);
+int wino_mode();
 
 // ---- wave / block reductions (wave = 64 lanes on gfx950) --------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

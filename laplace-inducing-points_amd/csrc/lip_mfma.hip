@@ -1091,6 +1091,208 @@ __global__ __launch_bounds__(256) void igemm_adirect_kernel(const IgemmP prm) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) implicit GEMM (round 3) for the 3x3 / stride 1 / pad 1 layers of the tangent and backward tapes
+// — 95 % of a CIFAR-net sweep's FLOPs.  Y = A^T [ (G w G^T) (.) (B^T d B) ] A per 2x2 output patch: 16 positions
+// xi = (a, b), each a GEMM over channels  M_xi[tile][n] = sum_c V_xi[tile][c] U_xi[c][n]  — 4 multiplications per
+// output pixel and (c, n) where the direct form needs 9, on the same v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate;
+// the transforms add 8 f32 additions per operand and move the result by ~2e-7 relative per layer, scripts/micro/
+// wino_probe.hip).  One block = 32 tiles (128 output pixels) x 32 TN columns; wave a owns row a of the transformed patch:
+//   * A operand: lane (tile i, half h) loads the 2 x 4 pixels of rows r1(a), r2(a) of its tile's 4x4 input patch, 4
+//     channels each (buffer_load_dwordx4; out-of-image pixels are dropped by the range check of the buffer descriptor),
+//     forms V[a][0..3] in registers = the A registers of 16 MFMAs (k-step (g, j): lane half h <-> channel 8g + 4h + j);
+//   * B operand: the transformed weights U, stored [xi][C/4][N][4] by wino_weight_transform_kernel so that lane (n, h)
+//     reads its 4 channels of U_xi[.][n] as ONE dwordx4 straight into the MFMA registers (512 contiguous bytes per
+//     half-wave); no LDS and no barrier in the channel loop;
+//   * output transform: over b inside the wave, over a across the four waves through LDS; wave w then owns output
+//     pixel (w >> 1, w & 1) of every tile and runs the SAME fused epilogue as the direct kernels (its parity-class row
+//     map is exactly "pixel (ph, pw) of tile t").
+// Several K-segments (tangent: conv(da, W) + conv(a, dW_p)) accumulate in the transformed domain: one output transform.
+// Mode-1 segments (data gradient, stride 1) are the same correlation with the kernel flipped — the weight transform does it.
+// Never used for the primal tape (ReLU gates / pooling arg-maxima are taken from the direct sums).
+// ------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+struct WinoX { unsigned a_bytes[3]; unsigned u_bytes[3]; };
+
+// U[xi = 4a + b][c / 4][n][c % 4] = (G w G^T)[a][b] of the 3x3 kernel w[kh][kw][c][n]  (flip: w[2-kh][2-kw])
+__global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ w, long long w_ps, float* __restrict__ u,
+                                                                     long long u_ps, int C, int N, int flip) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= C * N) return;
+  const int c = e / N, n = e - c * N;
+  const float* wp = w + (long long)blockIdx.y * w_ps;
+  float* up = u + (long long)blockIdx.y * u_ps;
+  float g[3][3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int sh = flip ? 2 - kh : kh, sw = flip ? 2 - kw : kw;
+      g[kh][kw] = wp[((long long)(sh * 3 + sw) * C + c) * N + n];
+    }
+  float t[4][3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    t[0][kw] = g[0][kw];
+    t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
+    t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
+    t[3][kw] = g[2][kw];
+  }
+  const int c4 = C >> 2;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float vv[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) up[(((long long)(4 * a + b) * c4 + (c >> 2)) * N + n) * 4 + (c & 3)] = vv[b];
+  }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void igemm_wino_kernel(const IgemmP prm, const WinoX wx) {
+  extern __shared__ float wino_lds[];              // exchange [4 a][2 q][TN][16 reg][64 lane], then redbuf [2 BN]
+  constexpr int BN = 32 * TN;
+  float* redbuf = wino_lds + 8 * TN * 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int N = prm.N;
+  const int nb = N / BN;
+  int bid = blockIdx.x, byp = blockIdx.y;
+  {   // XCD-contiguous order, as in igemm_fast_kernel
+    const int gx = (int)gridDim.x;
+    if (gx >= 64) {
+      const int g8 = gx & ~7;
+      if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+    } else {
+      const int g8 = (gx * (int)gridDim.y) & ~7, lin = bid + gx * byp;
+      if (lin < g8) {
+        const int w = (lin & 7) * (g8 >> 3) + (lin >> 3);
+        byp = w / gx; bid = w - byp * gx;
+      }
+    }
+  }
+  const int tb = bid / nb, cb = bid - tb * nb;
+  const int p = byp;
+  const int n0 = cb * BN;
+  for (int i = tid; i < 2 * BN; i += 256) redbuf[i] = 0.f;
+
+  const int W = prm.OW, H = prm.OHW / prm.OW;
+  const int t = tb * 32 + l31;
+  const bool tv = t < prm.Rc;
+  const int img = prm.dOHW2.div(t), rem = t - img * prm.OHW2;
+  const int ty = prm.dOW2.div(rem), tx = rem - ty * prm.OW2;
+  // rows of the 4x4 patch this wave's transform row needs:  e = d[r1] + sg d[r2]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
+  const int r1 = (a == 0) ? 0 : (a == 2 ? 2 : 1);
+  const int r2 = (a == 0) ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));
+  const float sg = (a == 1) ? 1.f : -1.f;
+  int pix[8];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int ih = 2 * ty - 1 + (rr ? r2 : r1);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int iw = 2 * tx - 1 + cc;
+      const bool ok = tv && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      pix[4 * rr + cc] = ok ? (img * H + ih) * W + iw : -1;
+    }
+  }
+
+  f32x16 acc[4][TN];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][tn][r] = 0.f;
+
+  for (int seg = 0; seg < prm.nseg; ++seg) {
+    const SegP& s = prm.seg[seg];
+    const int C = s.C, c4 = C >> 2, G = C >> 3;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.a + (long long)p * s.a_ps), 0, wx.a_bytes[seg], 0x00020000);
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.b + (long long)p * s.b_ps), 0, wx.u_bytes[seg], 0x00020000);
+    unsigned voff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) voff[q] = pix[q] >= 0 ? (unsigned)((pix[q] * C + 4 * h) * 4) : 0x80000000u;
+    const unsigned uvoff = (unsigned)((((4 * a) * c4 + h) * N + n0 + l31) * 16);
+    const unsigned ub_stride = (unsigned)(c4 * N * 16), ug_stride = (unsigned)(2 * N * 16);
+    f32x4v raw[8], bq[2][4][TN];
+    // (the loads are cast to float vectors whole: element access through __builtin_bit_cast(float, v[j]) on the
+    //  unsigned vector the builtin returns is miscompiled by hipcc 7.2 — only element 0 survives)
+    auto load_a = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) raw[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[q], g * 32, 0));
+    };
+    auto load_b = [&](int g, f32x4v (&dst)[4][TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          dst[b][tn] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(ursrc, uvoff, b * ub_stride + g * ug_stride + tn * 512, 0));
+    };
+    auto transform = [&](float (&v)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float e[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) e[cc] = fmaf(sg, raw[4 + cc][j], raw[cc][j]);
+        v[0][j] = e[0] - e[2]; v[1][j] = e[1] + e[2]; v[2][j] = e[2] - e[1]; v[3][j] = e[1] - e[3];
+      }
+    };
+    auto sweep = [&](const float (&v)[4][4], const f32x4v (&bc)[4][TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[b][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][j], bc[b][tn][j], acc[b][tn], 0, 0, 0);
+    };
+    // branch-free channel loop (C % 16 == 0: an even number of 8-channel groups); the last iteration re-requests the
+    // final group instead of testing for the end (a conditional load made the compiler spill the accumulators to VGPR
+    // copies every iteration)
+    load_a(0);
+    load_b(0, bq[0]);
+    for (int g = 0; g < G; g += 2) {
+      float v[4][4];
+      transform(v);
+      load_a(g + 1);
+      load_b(g + 1, bq[1]);
+      sweep(v, bq[0]);
+      transform(v);
+      const int gn = (g + 2 < G) ? g + 2 : G - 1;
+      load_a(gn);
+      load_b(gn, bq[0]);
+      sweep(v, bq[1]);
+    }
+  }
+
+  // output transform, in-wave part (A^T rows: m0+m1+m2, m1-m2-m3 over b) ...
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][tn][r], m1 = acc[1][tn][r], m2 = acc[2][tn][r], m3 = acc[3][tn][r];
+      wino_lds[(((a * 2 + 0) * TN + tn) * 16 + r) * 64 + lane] = m0 + m1 + m2;
+      wino_lds[(((a * 2 + 1) * TN + tn) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+    }
+  }
+  __syncthreads();
+  // ... and across the waves over a: wave w owns output pixel (po, qo) of every tile
+  const int po = a >> 1, qo = a & 1;
+  f32x16 y[1][TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float t1 = wino_lds[(((1 * 2 + qo) * TN + tn) * 16 + r) * 64 + lane];
+      const float t2 = wino_lds[(((2 * 2 + qo) * TN + tn) * 16 + r) * 64 + lane];
+      const float t03 = wino_lds[((((po ? 3 : 0) * 2 + qo) * TN + tn) * 16 + r) * 64 + lane];
+      y[0][tn][r] = po ? (t1 - t2 - t03) : (t03 + t1 + t2);
+    }
+  }
+  igemm_epilogue<1, 1, 1, TN, true>(prm, y, redbuf, p, tb * 32, n0, 0, 0, lane, tid, po, qo);
+}
+
+// ------------------------------------------------------------------------------------------
 // first layer of a conv net (round 3): ONE K-segment with a short reduction (K = KH KW C <= 64: 3 x 3 x 3 = 27 for the
 // CIFAR nets), the A operand the PRIMAL input — shared by all probes — and 32 output columns.  The generic kernel ran it
 // at 23 TFLOP/s (0.98 ms per 256-probe block): per probe it re-gathers the same 27-deep im2col rows.  Here a wave
@@ -2352,8 +2554,85 @@ static int cu_count() {
   return n;
 }
 
+// Winograd route of the 3x3 / stride-1 layers: -1 = not set (environment: LIP_NOWINO -> off, LIP_WINO=force -> every
+// eligible launch), 0 = off, 1 = auto (launches that fill the chip), 2 = force
+static int g_wino = -1;
+void set_wino_mode(int m) { g_wino = (m < 0 || m > 2) ? 1 : m; }
+int wino_mode() {
+  if (g_wino < 0) {
+    const char* f = getenv("LIP_WINO");
+    g_wino = getenv("LIP_NOWINO") ? 0 : ((f && f[0] == 'f') ? 2 : 1);
+  }
+  return g_wino;
+}
+
+static bool igemm_wino_ok(const IgemmP& p, int P) {
+  const int mode = wino_mode();
+  if (mode == 0 || precision_mode() != 0 || p.no_ksplit) return false;
+  if (p.nseg < 1 || p.N < 32 || (p.N & 31) != 0) return false;
+  const int OH = p.OHW / p.OW;
+  if ((OH & 1) || (p.OW & 1) || OH * p.OW != p.OHW) return false;
+  const long long n_img = p.R / p.OHW;
+  for (int s = 0; s < p.nseg; ++s) {
+    const SegP& q = p.seg[s];
+    if (q.KH != 3 || q.KW != 3 || q.stride != 1 || q.pad_h != 1 || q.pad_w != 1 || q.b_trans) return false;
+    if (q.IH != OH || q.IW != p.OW || (q.C & 15) != 0 || (q.mode != 0 && q.mode != 1)) return false;
+    if ((((uintptr_t)q.a) & 15) || (q.a_ps & 3) || (((uintptr_t)q.b) & 3)) return false;
+    if (n_img * p.OHW * q.C * 4 >= (1ll << 31) || 16ll * q.C * p.N * 4 >= (1ll << 31)) return false;
+  }
+  if (mode == 2) return true;
+  const int TN = (p.N & 63) == 0 ? 2 : 1;
+  const long long blocks = (long long)((p.R / 4 + 31) / 32) * (p.N / (32 * TN)) * P;
+  return blocks >= 4ll * cu_count();
+}
+
+template <int TN>
+static hipError_t run_igemm_wino(const IgemmP& p, int P, hipStream_t st) {
+  IgemmP q = p;
+  WinoX wx;
+  const int OH = p.OHW / p.OW;
+  const long long n_img = p.R / p.OHW;
+  size_t need = 0;
+  for (int s = 0; s < p.nseg; ++s) need += (size_t)(p.seg[s].b_ps ? P : 1) * 16 * p.seg[s].C * p.N;
+  float* scratch = ksplit_scratch(need, st);
+  if (!scratch) return hipErrorOutOfMemory;
+  size_t off = 0;
+  for (int s = 0; s < p.nseg; ++s) {
+    const SegP& g = p.seg[s];
+    const long long un = 16ll * g.C * p.N;
+    const int PW = g.b_ps ? P : 1;
+    hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)((g.C * p.N + 255) / 256), (unsigned)PW), dim3(256), 0, st,
+                       g.b, g.b_ps, scratch + off, un, g.C, p.N, g.mode == 1 ? 1 : 0);
+    q.seg[s].b = scratch + off;
+    q.seg[s].b_ps = g.b_ps ? un : 0;
+    wx.a_bytes[s] = (unsigned)(n_img * p.OHW * g.C * 4);
+    wx.u_bytes[s] = (unsigned)(un * 4);
+    off += (size_t)PW * un;
+  }
+  for (int s = p.nseg; s < 3; ++s) { wx.a_bytes[s] = 0; wx.u_bytes[s] = 0; }
+  q.OW2 = p.OW / 2; q.OHW2 = (OH / 2) * q.OW2; q.Rc = (int)(n_img * q.OHW2);
+  q.dOHW2 = FastDiv((unsigned)q.OHW2); q.dOW2 = FastDiv((unsigned)q.OW2);
+  q.zeros = nullptr; q.dbg = nullptr; q.partial = nullptr;
+  const size_t shmem = (size_t)(8 * TN * 1024 + 2 * 32 * TN) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_wino_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(((q.Rc + 31) / 32) * (p.N / (32 * TN))), (unsigned)P, 1);
+  hipLaunchKernelGGL((igemm_wino_kernel<TN>), grid, dim3(256), shmem, st, q, wx);
+  return hipGetLastError();
+}
+
 hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   if (igemm_first_ok(p, P)) return run_igemm_first(p, P, st);
+  if (igemm_wino_ok(p, P)) {
+    // (no scratch for the transformed weights — a 17th stream, or the allocation failed: the direct kernels below)
+    const hipError_t e = (p.N & 63) == 0 ? run_igemm_wino<2>(p, P, st) : run_igemm_wino<1>(p, P, st);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+  }
   // Few probes (single-vector Krylov loops): with fewer 128-row blocks than CUs the launch time is ONE block's K loop,
   // so take the tiles with the least work per wave (32x32 per wave, 64-row blocks) — at P = 1 the 128-channel layers
   // of the CIFAR net run 25 blocks of 144 K-tiles otherwise (measured 177 us per launch).  A/B switch LIP_NOSMALLP.

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"liblip_hip.so does not export {n}"
         assert n in nv.SIGNATURES, f"ctypes binding lacks a signature for {n}"
-    assert lib.lip_abi_version() == 7
+    assert lib.lip_abi_version() == 8
     assert lib.lip_sizeof_op() == ctypes.sizeof(nv.Op)
 
 
