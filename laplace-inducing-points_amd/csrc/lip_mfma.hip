@@ -222,13 +222,18 @@ __device__ __forceinline__ void pipelined_k_loop(int T, float* As, float* Bs, Lo
 #ifndef LIP_EPI_PHASE
 #define LIP_EPI_PHASE 8
 #endif
-template <int WM, int WN, int TM, int TN, bool PAR = false>
+// PAR == 2 (Winograd): the block's 32 accumulator rows are tiles; `rowtab[i]` (LDS) holds the tensor row of pixel (0, 0)
+// of tile i or -1, the wave writes pixel (ph, pw) of every tile, `tab_full` says that no tile of the block is masked.
+template <int WM, int WN, int TM, int TN, int PAR = 0>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[TM][TN], float* redbuf, int p, int r0,
-                                               int n0, int wm, int wn, int lane, int tid, int ph = 0, int pw = 0) {
+                                               int n0, int wm, int wn, int lane, int tid, int ph = 0, int pw = 0,
+                                               const int* rowtab = nullptr, bool tab_full = false) {
   using T = Tile<WM, WN, TM, TN>;
   constexpr int NT = T::NT, BN = T::BN;
-  const int N = prm.N, R = PAR ? prm.Rc : prm.R;
+  const int N = prm.N, R = PAR == 1 ? prm.Rc : prm.R;
+  const int tab_shift = ph * prm.OW + pw;
   auto row_of = [&](int r) -> int {
+    if (PAR == 2) return rowtab[r] + tab_shift;
     if (!PAR) return r;
     const int i = prm.dOHW2.div(r), rem = r - i * prm.OHW2;
     const int a = prm.dOW2.div(rem), b = rem - a * prm.OW2;
@@ -243,7 +248,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
   float* __restrict__ out = prm.out + (long long)p * prm.out_ps;
   const bool has_e1 = prm.e1 != nullptr, has_r1 = prm.red1 != nullptr;
   constexpr int PH = LIP_EPI_PHASE;                   // accumulator rows drained per phase
-  const bool full_tile = (r0 + WM * TM * 32 <= R) && (n0 + BN <= N);      // uniform: no row / column of the block is masked
+  const bool full_tile = PAR == 2 ? (tab_full && (n0 + BN <= N)) : ((r0 + WM * TM * 32 <= R) && (n0 + BN <= N));      // uniform: no row / column of the block is masked
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int cl = (wn * TN + tn) * 32 + l31;
@@ -268,7 +273,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& prm, f32x16 (&acc)[
         for (int q = 0; q < PH; ++q) {
           const int reg = PH * h + q;
           const int r = rbase + (reg & 3) + 8 * (reg >> 2);
-          ok[q] = cv && r < R;
+          ok[q] = cv && (PAR == 2 ? rowtab[r] >= 0 : r < R);
           idx[q] = ok[q] ? (unsigned)(row_of(r) * N + col) : 0u;               // clamped: loads stay unconditional
         }
         if (has_e1) {
@@ -1095,23 +1100,33 @@ __global__ __launch_bounds__(256) void igemm_adirect_kernel(const IgemmP prm) {
 // — 95 % of a CIFAR-net sweep's FLOPs.  Y = A^T [ (G w G^T) (.) (B^T d B) ] A per 2x2 output patch: 16 positions
 // xi = (a, b), each a GEMM over channels  M_xi[tile][n] = sum_c V_xi[tile][c] U_xi[c][n]  — 4 multiplications per
 // output pixel and (c, n) where the direct form needs 9, on the same v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate;
-// the transforms add 8 f32 additions per operand and move the result by ~2e-7 relative per layer, scripts/micro/
-// wino_probe.hip).  One block = 32 tiles (128 output pixels) x 32 TN columns; wave a owns row a of the transformed patch:
-//   * A operand: lane (tile i, half h) loads the 2 x 4 pixels of rows r1(a), r2(a) of its tile's 4x4 input patch, 4
-//     channels each (buffer_load_dwordx4; out-of-image pixels are dropped by the range check of the buffer descriptor),
-//     forms V[a][0..3] in registers = the A registers of 16 MFMAs (k-step (g, j): lane half h <-> channel 8g + 4h + j);
+// the transforms add 8 f32 additions per operand and move a layer's result by ~2e-7 relative, scripts/micro/
+// wino_probe.hip).  One block = 32 tiles (128 output pixels: NI images x BH x BW tiles, a rectangle so that the input
+// footprint is small) x 32 columns; wave a owns row a of the 4x4 transformed patch:
+//   * A operand: the block's input footprint (NI x (2 BH + 2) x (2 BW + 2) pixels, 32 channels per chunk) goes
+//     global -> registers -> LDS in WHOLE 128-byte lines (8 lanes per pixel; out-of-image pixels are dropped by the range
+//     check of the buffer descriptor and arrive as zeros), pixel slots padded to 144 bytes; lane (tile i, half h) reads
+//     the 2 x 4 pixels of rows r1(a), r2(a) of its tile's patch, 4 channels each (ds_read_b128), and forms V[a][0..3] in
+//     registers = the A registers of 16 MFMAs (k-step (g, j): lane half h <-> channel 8g + 4h + j).  The first version
+//     fetched those 16-byte pieces straight from global memory — 32 different lines per lane-instruction: its speed was
+//     set by line fills and load latency, not by the matrix pipe (timing ablation: every lane reading pixel 0 ran
+//     1.4 - 2.0x faster); the LDS-staged form: 2.31 -> 1.72 / 1.54 -> 1.32 / 1.29 -> 1.14 ms on the three CIFAR stages;
 //   * B operand: the transformed weights U, stored [xi][C/4][N][4] by wino_weight_transform_kernel so that lane (n, h)
 //     reads its 4 channels of U_xi[.][n] as ONE dwordx4 straight into the MFMA registers (512 contiguous bytes per
-//     half-wave); no LDS and no barrier in the channel loop;
+//     half-wave), requested one group ahead (a scheduling barrier keeps the compiler from sinking the loads to their
+//     uses: with them there a group of 16 MFMAs took 5 k cycles);
 //   * output transform: over b inside the wave, over a across the four waves through LDS; wave w then owns output
-//     pixel (w >> 1, w & 1) of every tile and runs the SAME fused epilogue as the direct kernels (its parity-class row
-//     map is exactly "pixel (ph, pw) of tile t").
+//     pixel (w >> 1, w & 1) of every tile and runs the SAME fused epilogue as the direct kernels (row table in LDS).
 // Several K-segments (tangent: conv(da, W) + conv(a, dW_p)) accumulate in the transformed domain: one output transform.
 // Mode-1 segments (data gradient, stride 1) are the same correlation with the kernel flipped — the weight transform does it.
 // Never used for the primal tape (ReLU gates / pooling arg-maxima are taken from the direct sums).
 // ------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-struct WinoX { unsigned a_bytes[3]; unsigned u_bytes[3]; };
+struct WinoX {
+  unsigned a_bytes[3]; unsigned u_bytes[3];
+  int BWs, BHs, NI, FR, FC, nbx, nby, NS, n_img, TH, TW;
+  float inv_frfc, inv_fc;
+};
 
 // U[xi = 4a + b][c / 4][n][c % 4] = (G w G^T)[a][b] of the 3x3 kernel w[kh][kw][c][n]  (flip: w[2-kh][2-kw])
 __global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ w, long long w_ps, float* __restrict__ u,
@@ -1146,11 +1161,15 @@ __global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float*
   }
 }
 
-template <int TN>
+constexpr int WINO_SLOTS = 224;     // LDS pixel slots of the staged footprint (9 x 16 bytes each)
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void igemm_wino_kernel(const IgemmP prm, const WinoX wx) {
-  extern __shared__ float wino_lds[];              // exchange [4 a][2 q][TN][16 reg][64 lane], then redbuf [2 BN]
-  constexpr int BN = 32 * TN;
-  float* redbuf = wino_lds + 8 * TN * 1024;
+  // stage [WINO_SLOTS][36] floats, later the exchange [4 a][2 q][16 reg][64 lane] (aliased); then rowtab[32], redbuf[64]
+  extern __shared__ __attribute__((aligned(16))) float wino_lds[];
+  constexpr int BN = 32;
+  int* rowtab = reinterpret_cast<int*>(wino_lds + 8192);
+  float* redbuf = wino_lds + 8192 + 32;
+  f32x4v* lds4 = reinterpret_cast<f32x4v*>(wino_lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
@@ -1170,126 +1189,149 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
       }
     }
   }
-  const int tb = bid / nb, cb = bid - tb * nb;
+  const int tbid = bid / nb, cb = bid - tbid * nb;
+  const int bxy = wx.nbx * wx.nby;
+  const int bi = tbid / bxy, brem = tbid - bi * bxy;
+  const int by = brem / wx.nbx, bx = brem - by * wx.nbx;
   const int p = byp;
   const int n0 = cb * BN;
-  for (int i = tid; i < 2 * BN; i += 256) redbuf[i] = 0.f;
+  if (tid < 2 * BN) redbuf[tid] = 0.f;
 
   const int W = prm.OW, H = prm.OHW / prm.OW;
-  const int t = tb * 32 + l31;
-  const bool tv = t < prm.Rc;
-  const int img = prm.dOHW2.div(t), rem = t - img * prm.OHW2;
-  const int ty = prm.dOW2.div(rem), tx = rem - ty * prm.OW2;
+  const int BW = 1 << wx.BWs, BH = 1 << wx.BHs, FR = wx.FR, FC = wx.FC;
+  // this lane's tile
+  const int ni = l31 >> (wx.BWs + wx.BHs), dy = (l31 >> wx.BWs) & (BH - 1), dx = l31 & (BW - 1);
+  {
+    const int img = bi * wx.NI + ni, ty = by * BH + dy, tx = bx * BW + dx;
+    const bool tv = img < wx.n_img && ty < wx.TH && tx < wx.TW;
+    if (tid < 32) rowtab[tid] = tv ? (img * H + 2 * ty) * W + 2 * tx : -1;
+  }
+  const bool blk_full = (bi * wx.NI + wx.NI <= wx.n_img) && (by * BH + BH <= wx.TH) && (bx * BW + BW <= wx.TW);
   // rows of the 4x4 patch this wave's transform row needs:  e = d[r1] + sg d[r2]   (B^T rows: d0-d2, d1+d2, d2-d1, d1-d3)
   const int r1 = (a == 0) ? 0 : (a == 2 ? 2 : 1);
   const int r2 = (a == 0) ? 2 : (a == 1 ? 2 : (a == 2 ? 1 : 3));
   const float sg = (a == 1) ? 1.f : -1.f;
-  int pix[8];
+  const int rq1 = ((ni * FR + 2 * dy + r1) * FC + 2 * dx) * 9 + h;          // LDS read bases in 16-byte units
+  const int rq2 = ((ni * FR + 2 * dy + r2) * FC + 2 * dx) * 9 + h;
+  // staging: thread -> (pixel slot, 16-byte part) x 7
+  const int part = tid & 7;
+  int spix[7];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int ih = 2 * ty - 1 + (rr ? r2 : r1);
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int iw = 2 * tx - 1 + cc;
-      const bool ok = tv && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-      pix[4 * rr + cc] = ok ? (img * H + ih) * W + iw : -1;
-    }
+  for (int j = 0; j < 7; ++j) {
+    const int slot = (tid >> 3) + 32 * j;
+    const int sni = (int)(((float)slot + 0.5f) * wx.inv_frfc), srem = slot - sni * FR * FC;     // exact: slot < 256
+    const int fr = (int)(((float)srem + 0.5f) * wx.inv_fc), fc = srem - fr * FC;
+    const int simg = bi * wx.NI + sni, ih = 2 * by * BH - 1 + fr, iw = 2 * bx * BW - 1 + fc;
+    const bool ok = slot < wx.NS && simg < wx.n_img && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    spix[j] = ok ? (simg * H + ih) * W + iw : -1;
   }
 
-  f32x16 acc[4][TN];
+  f32x16 acc[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[b][tn][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-  for (int seg = 0; seg < prm.nseg; ++seg) {
+  f32x4v sreg[7], bq[2][4];
+  // (buffer loads are cast to float vectors whole: element access through __builtin_bit_cast(float, v[j]) on the
+  //  unsigned vector the builtin returns is miscompiled by hipcc 7.2 — only element 0 survives)
+  auto stage_load = [&](int seg, int k) __attribute__((always_inline)) {
     const SegP& s = prm.seg[seg];
-    const int C = s.C, c4 = C >> 2, G = C >> 3;
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.a + (long long)p * s.a_ps), 0, wx.a_bytes[seg], 0x00020000);
-    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.b + (long long)p * s.b_ps), 0, wx.u_bytes[seg], 0x00020000);
-    unsigned voff[8];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.a + (long long)p * s.a_ps), 0, wx.a_bytes[seg], 0x00020000);
+    const int C = s.C;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) voff[q] = pix[q] >= 0 ? (unsigned)((pix[q] * C + 4 * h) * 4) : 0x80000000u;
+    for (int j = 0; j < 7; ++j) {
+      const unsigned vo = spix[j] >= 0 ? (unsigned)((spix[j] * C + 4 * part) * 4) : 0x80000000u;
+      sreg[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, k * 128, 0));
+    }
+  };
+  auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int slot = (tid >> 3) + 32 * j;
+      if (slot < WINO_SLOTS) lds4[slot * 9 + part] = sreg[j];
+    }
+  };
+  auto load_b = [&](int seg, int g, f32x4v (&dst)[4]) __attribute__((always_inline)) {
+    const SegP& s = prm.seg[seg];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.b + (long long)p * s.b_ps), 0, wx.u_bytes[seg], 0x00020000);
+    const int c4 = s.C >> 2;
     const unsigned uvoff = (unsigned)((((4 * a) * c4 + h) * N + n0 + l31) * 16);
     const unsigned ub_stride = (unsigned)(c4 * N * 16), ug_stride = (unsigned)(2 * N * 16);
-    f32x4v raw[8], bq[2][4][TN];
-    // (the loads are cast to float vectors whole: element access through __builtin_bit_cast(float, v[j]) on the
-    //  unsigned vector the builtin returns is miscompiled by hipcc 7.2 — only element 0 survives)
-    auto load_a = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) raw[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[q], g * 32, 0));
-    };
-    auto load_b = [&](int g, f32x4v (&dst)[4][TN]) __attribute__((always_inline)) {
+    for (int b = 0; b < 4; ++b) dst[b] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, uvoff, b * ub_stride + g * ug_stride, 0));
+  };
+  // one 8-channel group: patch pixels from LDS, the NEXT group's B requested, then (behind a scheduling barrier) the
+  // input transform and the 16 MFMAs
+  auto group = [&](int g, int seg_n, int g_n, const f32x4v (&bc)[4], f32x4v (&bn)[4]) __attribute__((always_inline)) {
+    float v[4][4];
+    f32x4v raw[8];
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+    for (int cc = 0; cc < 4; ++cc) {
+      raw[cc] = lds4[rq1 + cc * 9 + 2 * g];
+      raw[4 + cc] = lds4[rq2 + cc * 9 + 2 * g];
+    }
+    load_b(seg_n, g_n, bn);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          dst[b][tn] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(ursrc, uvoff, b * ub_stride + g * ug_stride + tn * 512, 0));
-    };
-    auto transform = [&](float (&v)[4][4]) __attribute__((always_inline)) {
+    for (int j = 0; j < 4; ++j) {
+      float e[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float e[4];
+      for (int cc = 0; cc < 4; ++cc) e[cc] = fmaf(sg, raw[4 + cc][j], raw[cc][j]);
+      v[0][j] = e[0] - e[2]; v[1][j] = e[1] + e[2]; v[2][j] = e[2] - e[1]; v[3][j] = e[1] - e[3];
+    }
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) e[cc] = fmaf(sg, raw[4 + cc][j], raw[cc][j]);
-        v[0][j] = e[0] - e[2]; v[1][j] = e[1] + e[2]; v[2][j] = e[2] - e[1]; v[3][j] = e[1] - e[3];
-      }
-    };
-    auto sweep = [&](const float (&v)[4][4], const f32x4v (&bc)[4][TN]) __attribute__((always_inline)) {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[b][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][j], bc[b][tn][j], acc[b][tn], 0, 0, 0);
-    };
-    // branch-free channel loop (C % 16 == 0: an even number of 8-channel groups); the last iteration re-requests the
-    // final group instead of testing for the end (a conditional load made the compiler spill the accumulators to VGPR
-    // copies every iteration)
-    load_a(0);
-    load_b(0, bq[0]);
-    for (int g = 0; g < G; g += 2) {
-      float v[4][4];
-      transform(v);
-      load_a(g + 1);
-      load_b(g + 1, bq[1]);
-      sweep(v, bq[0]);
-      transform(v);
-      const int gn = (g + 2 < G) ? g + 2 : G - 1;
-      load_a(gn);
-      load_b(gn, bq[0]);
-      sweep(v, bq[1]);
+      for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[b][j], bc[b][j], acc[b], 0, 0, 0);
+  };
+
+  stage_load(0, 0);
+  load_b(0, 0, bq[0]);
+  const int nseg = prm.nseg;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const int chunks = prm.seg[seg].C >> 5, GT = prm.seg[seg].C >> 3;
+    const bool more_seg = seg + 1 < nseg;
+    for (int k = 0; k < chunks; ++k) {
+      stage_store();
+      __syncthreads();
+      const int g0 = 4 * k;
+      const bool last = k + 1 == chunks;
+      // what follows this chunk: the next chunk of the segment, the first of the next segment, or (at the very end) this
+      // chunk again — a redundant request instead of a branch in the loop
+      const int seg_n = (last && more_seg) ? seg + 1 : seg;
+      const int k_n = last ? (more_seg ? 0 : k) : k + 1;
+      const int g_n = last ? (more_seg ? 0 : GT - 1) : g0 + 4;
+      __builtin_amdgcn_sched_barrier(0);
+      group(0, seg, g0 + 1, bq[0], bq[1]);
+      group(1, seg, g0 + 2, bq[1], bq[0]);
+      group(2, seg, g0 + 3, bq[0], bq[1]);
+      group(3, seg_n, g_n, bq[1], bq[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_load(seg_n, k_n);
+      __syncthreads();
     }
   }
 
   // output transform, in-wave part (A^T rows: m0+m1+m2, m1-m2-m3 over b) ...
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float m0 = acc[0][tn][r], m1 = acc[1][tn][r], m2 = acc[2][tn][r], m3 = acc[3][tn][r];
-      wino_lds[(((a * 2 + 0) * TN + tn) * 16 + r) * 64 + lane] = m0 + m1 + m2;
-      wino_lds[(((a * 2 + 1) * TN + tn) * 16 + r) * 64 + lane] = m1 - m2 - m3;
-    }
+  for (int r = 0; r < 16; ++r) {
+    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+    wino_lds[((a * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
+    wino_lds[((a * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
   }
   __syncthreads();
   // ... and across the waves over a: wave w owns output pixel (po, qo) of every tile
   const int po = a >> 1, qo = a & 1;
-  f32x16 y[1][TN];
+  f32x16 y[1][1];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float t1 = wino_lds[(((1 * 2 + qo) * TN + tn) * 16 + r) * 64 + lane];
-      const float t2 = wino_lds[(((2 * 2 + qo) * TN + tn) * 16 + r) * 64 + lane];
-      const float t03 = wino_lds[((((po ? 3 : 0) * 2 + qo) * TN + tn) * 16 + r) * 64 + lane];
-      y[0][tn][r] = po ? (t1 - t2 - t03) : (t03 + t1 + t2);
-    }
+  for (int r = 0; r < 16; ++r) {
+    const float t1 = wino_lds[((1 * 2 + qo) * 16 + r) * 64 + lane];
+    const float t2 = wino_lds[((2 * 2 + qo) * 16 + r) * 64 + lane];
+    const float t03 = wino_lds[(((po ? 3 : 0) * 2 + qo) * 16 + r) * 64 + lane];
+    y[0][0][r] = po ? (t1 - t2 - t03) : (t03 + t1 + t2);
   }
-  igemm_epilogue<1, 1, 1, TN, true>(prm, y, redbuf, p, tb * 32, n0, 0, 0, lane, tid, po, qo);
+  igemm_epilogue<1, 1, 1, 1, 2>(prm, y, redbuf, p, 0, n0, 0, 0, lane, tid, po, qo, rowtab, blk_full);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2566,6 +2608,19 @@ int wino_mode() {
   return g_wino;
 }
 
+struct WinoGeom { int BWs, BHs, NI, FR, FC, nbx, nby, nbi, NS, TH, TW; };
+static WinoGeom wino_geom(int OH, int OW, long long n_img) {
+  WinoGeom g;
+  g.TH = OH / 2; g.TW = OW / 2;
+  g.BWs = 0; while ((1 << g.BWs) < g.TW && g.BWs < 4) ++g.BWs;
+  g.BHs = 0; while ((1 << g.BHs) < g.TH && g.BWs + g.BHs < 5) ++g.BHs;
+  g.NI = 32 >> (g.BWs + g.BHs);
+  g.FR = 2 * (1 << g.BHs) + 2; g.FC = 2 * (1 << g.BWs) + 2; g.NS = g.NI * g.FR * g.FC;
+  g.nbx = (g.TW + (1 << g.BWs) - 1) >> g.BWs; g.nby = (g.TH + (1 << g.BHs) - 1) >> g.BHs;
+  g.nbi = (int)((n_img + g.NI - 1) / g.NI);
+  return g;
+}
+
 static bool igemm_wino_ok(const IgemmP& p, int P) {
   const int mode = wino_mode();
   if (mode == 0 || precision_mode() != 0 || p.no_ksplit) return false;
@@ -2576,17 +2631,17 @@ static bool igemm_wino_ok(const IgemmP& p, int P) {
   for (int s = 0; s < p.nseg; ++s) {
     const SegP& q = p.seg[s];
     if (q.KH != 3 || q.KW != 3 || q.stride != 1 || q.pad_h != 1 || q.pad_w != 1 || q.b_trans) return false;
-    if (q.IH != OH || q.IW != p.OW || (q.C & 15) != 0 || (q.mode != 0 && q.mode != 1)) return false;
+    if (q.IH != OH || q.IW != p.OW || (q.C & 31) != 0 || (q.mode != 0 && q.mode != 1)) return false;
     if ((((uintptr_t)q.a) & 15) || (q.a_ps & 3) || (((uintptr_t)q.b) & 3)) return false;
     if (n_img * p.OHW * q.C * 4 >= (1ll << 31) || 16ll * q.C * p.N * 4 >= (1ll << 31)) return false;
   }
+  const WinoGeom g = wino_geom(OH, p.OW, n_img);
+  if (g.NS > WINO_SLOTS) return false;                 // (maps smaller than 8 x 8: the direct kernels)
   if (mode == 2) return true;
-  const int TN = (p.N & 63) == 0 ? 2 : 1;
-  const long long blocks = (long long)((p.R / 4 + 31) / 32) * (p.N / (32 * TN)) * P;
+  const long long blocks = (long long)g.nbx * g.nby * g.nbi * (p.N / 32) * P;
   return blocks >= 4ll * cu_count();
 }
 
-template <int TN>
 static hipError_t run_igemm_wino(const IgemmP& p, int P, hipStream_t st) {
   IgemmP q = p;
   WinoX wx;
@@ -2610,18 +2665,20 @@ static hipError_t run_igemm_wino(const IgemmP& p, int P, hipStream_t st) {
     off += (size_t)PW * un;
   }
   for (int s = p.nseg; s < 3; ++s) { wx.a_bytes[s] = 0; wx.u_bytes[s] = 0; }
-  q.OW2 = p.OW / 2; q.OHW2 = (OH / 2) * q.OW2; q.Rc = (int)(n_img * q.OHW2);
-  q.dOHW2 = FastDiv((unsigned)q.OHW2); q.dOW2 = FastDiv((unsigned)q.OW2);
+  const WinoGeom g = wino_geom(OH, p.OW, n_img);
+  wx.BWs = g.BWs; wx.BHs = g.BHs; wx.NI = g.NI; wx.FR = g.FR; wx.FC = g.FC; wx.nbx = g.nbx; wx.nby = g.nby; wx.NS = g.NS;
+  wx.n_img = (int)n_img; wx.TH = g.TH; wx.TW = g.TW;
+  wx.inv_frfc = 1.f / (float)(g.FR * g.FC); wx.inv_fc = 1.f / (float)g.FC;
   q.zeros = nullptr; q.dbg = nullptr; q.partial = nullptr;
-  const size_t shmem = (size_t)(8 * TN * 1024 + 2 * 32 * TN) * sizeof(float);
+  const size_t shmem = (size_t)(8192 + 32 + 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_wino_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid((unsigned)(((q.Rc + 31) / 32) * (p.N / (32 * TN))), (unsigned)P, 1);
-  hipLaunchKernelGGL((igemm_wino_kernel<TN>), grid, dim3(256), shmem, st, q, wx);
+  dim3 grid((unsigned)((long long)g.nbx * g.nby * g.nbi * (p.N / 32)), (unsigned)P, 1);
+  hipLaunchKernelGGL(igemm_wino_kernel, grid, dim3(256), shmem, st, q, wx);
   return hipGetLastError();
 }
 
@@ -2629,7 +2686,7 @@ hipError_t launch_igemm(const IgemmP& p, int P, hipStream_t st) {
   if (igemm_first_ok(p, P)) return run_igemm_first(p, P, st);
   if (igemm_wino_ok(p, P)) {
     // (no scratch for the transformed weights — a 17th stream, or the allocation failed: the direct kernels below)
-    const hipError_t e = (p.N & 63) == 0 ? run_igemm_wino<2>(p, P, st) : run_igemm_wino<1>(p, P, st);
+    const hipError_t e = run_igemm_wino(p, P, st);
     if (e != hipErrorOutOfMemory) return e;
     (void)hipGetLastError();
   }
