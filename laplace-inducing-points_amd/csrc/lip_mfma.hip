@@ -1994,7 +1994,9 @@ static bool wgrad_skinny_ok(const WgradP& p) {
          p.pad_w == 0 && p.KH == p.IH && p.KW == p.IW && (long long)p.R * p.M < (1ll << 31) && p.M >= 32 && p.N <= (1 << 20);
 }
 
-bool wgrad_will_overwrite(const WgradP& p, int P) { (void)P; return wgrad_skinny_ok(p); }
+static bool wgrad_wino_ok(const WgradP& p, int P);
+static int wgrad_wino_splits(const WgradP& p, int P);
+bool wgrad_will_overwrite(const WgradP& p, int P) { return wgrad_skinny_ok(p) || (wgrad_wino_ok(p, P) && wgrad_wino_splits(p, P) == 1); }
 
 template <int TM, int KK>
 static hipError_t run_wgrad_skinny(const WgradP& p0, int P, hipStream_t st) {
@@ -2112,6 +2114,229 @@ static hipError_t run_wgrad_first(const WgradP& p0, int P, hipStream_t st) {
   if (rsplit < 1) rsplit = 1;
   const long long items = (long long)P * rsplit;
   hipLaunchKernelGGL((wgrad_first_kernel<KC>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p, rsplit);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) WEIGHT GRADIENT (round 3) of the 3x3 / stride 1 / pad 1 layers:
+//   dW = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G  — 16 positions xi, each a GEMM with the reduction over TILES,
+//   dU_xi[c][n] = sum_t V_xi[t][c] Gh_xi[t][n]: 4 multiplications per output pixel and (c, n) instead of 9.
+//   * V = B^T a B of the PRIMAL activations is shared by all probes: wino_input_transform_kernel writes it once per
+//     launch as Vt[xi][t/4][c][4], so lane (c, half h) reads four consecutive tiles of its channel as ONE dwordx4 (512
+//     contiguous bytes per half-wave) — the A registers of 4 k-steps (k-step j multiplies tile 8m + 4h + j);
+//   * Gh = A g A^T of the probe's cotangent is formed on the fly: lane (n, h) loads the 2 x 2 pixels of its tile (dwords,
+//     128 contiguous bytes per half-wave), 2 + 3 VALU operations -> the B registers of its wave's four positions;
+//   * wave a owns row a of the 4x4 position grid (64 accumulator registers); dW = G^T dU G in-wave over b, across the
+//     waves over a through LDS; the fused output y = s acc + alpha v when one block reduces all tiles, float atomics
+//     into the initialised block when the tiles are split over blocks (few (c, n) tiles per probe: the 32-channel stage).
+// scripts/micro/wino_wgrad_probe.hip: 1.15 - 1.21 ms on the three CIFAR stages at 256 probes (direct kernels: 2.03 - 2.13).
+// ------------------------------------------------------------------------------------------
+struct WgWinoP {
+  const float* vt; unsigned vt_bytes;
+  const float* g; long long g_ps; unsigned g_bytes;
+  float* y; long long y_ps;
+  const float* scale; const float* v; long long v_ps; float alpha; int overwrite;
+  int H, W, C, N, TW, T, TQ, S, gps, tpi;
+  FastDiv dTPI, dTW;
+};
+
+// thread (tq, c): the 4x4 patches of tiles 4 tq .. 4 tq + 3, channel c -> 16 float4 (zeros past the last tile)
+__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ x, float* __restrict__ vt, int H, int W, int C,
+                                                                    int TH, int TW, int T, int TQ) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)TQ * C) return;
+  const int c = (int)(e % C), tq = (int)(e / C);
+  float v[16][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = 4 * tq + j;
+    float d[4][4];
+    const int img = t / (TH * TW), rem = t - img * TH * TW, ty = rem / TW, tx = rem - ty * TW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ih = 2 * ty - 1 + r, iw = 2 * tx - 1 + q;
+        d[r][q] = (t < T && ih >= 0 && ih < H && iw >= 0 && iw < W) ? x[((long long)(img * H + ih) * W + iw) * C + c] : 0.f;
+      }
+    float e4[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      e4[0][q] = d[0][q] - d[2][q]; e4[1][q] = d[1][q] + d[2][q]; e4[2][q] = d[2][q] - d[1][q]; e4[3][q] = d[1][q] - d[3][q];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      v[4 * a + 0][j] = e4[a][0] - e4[a][2]; v[4 * a + 1][j] = e4[a][1] + e4[a][2];
+      v[4 * a + 2][j] = e4[a][2] - e4[a][1]; v[4 * a + 3][j] = e4[a][1] - e4[a][3];
+    }
+  }
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+    *reinterpret_cast<f32x4v*>(&vt[(((long long)xi * TQ + tq) * C + c) * 4]) = f32x4v{v[xi][0], v[xi][1], v[xi][2], v[xi][3]};
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_wino_kernel(const WgWinoP prm) {
+  extern __shared__ __attribute__((aligned(16))) float wgw_lds[];          // [4 a][3 kw][16 reg][64 lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int C = prm.C, N = prm.N, W = prm.W, H = prm.H;
+  const int ctn = C >> 5, ntn = N >> 5;
+  int bid = blockIdx.x, byp = blockIdx.y;
+  {   // XCD-contiguous order: the blocks of one probe (they stream the same cotangent) share an L2
+    const int gx = (int)gridDim.x;
+    if (gx >= 64) {
+      const int g8 = gx & ~7;
+      if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+    } else {
+      const int g8 = (gx * (int)gridDim.y) & ~7, lin = bid + gx * byp;
+      if (lin < g8) {
+        const int w = (lin & 7) * (g8 >> 3) + (lin >> 3);
+        byp = w / gx; bid = w - byp * gx;
+      }
+    }
+  }
+  const int nt = bid % ntn; bid /= ntn;
+  const int ct = bid % ctn;
+  const int z = bid / ctn;                          // share of the tiles
+  const int p = byp;
+  const int c = ct * 32 + l31, n = nt * 32 + l31;
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prm.vt), 0, prm.vt_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prm.g + (long long)p * prm.g_ps), 0, prm.g_bytes, 0x00020000);
+  // rows of the 2x2 cotangent tile and their coefficients:  x_q = k0 g[0][q] + k1 g[1][q]   (A rows: g0, g0+g1, g0-g1, -g1)
+  const float k0 = (a == 3) ? 0.f : 1.f;
+  const float k1 = (a == 0) ? 0.f : (a == 1 ? 1.f : -1.f);
+  const unsigned avoff = (unsigned)((h * C + c) * 16);
+  const unsigned a_xi = (unsigned)prm.TQ * C * 16;            // bytes per position plane
+  const unsigned row_bytes = (unsigned)(W * N * 4);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int m0 = z * prm.gps, m1 = m0 + prm.gps;
+  f32x4v areg[2][4];
+  float graw[2][4][4];                 // [buffer][tile j][r * 2 + q]
+  auto load_group = [&](int m, f32x4v (&ar)[4], float (&gr)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      ar[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(vrs, avoff, (4 * a + q) * a_xi + (unsigned)(2 * m) * C * 16, 0));
+    const int t = 8 * m + 4 * h;                      // (TW % 4 == 0: the lane's four tiles share a tile row)
+    const int img = prm.dTPI.div(t), rem = t - img * prm.tpi, ty = prm.dTW.div(rem), tx = rem - ty * prm.TW;
+    const unsigned gv = t < prm.T ? (unsigned)((((img * H + 2 * ty) * W + 2 * tx) * N + n) * 4) : 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          gr[j][2 * r + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gv + (unsigned)((2 * j + q) * N * 4), r * row_bytes, 0));
+  };
+  auto compute = [&](const f32x4v (&ar)[4], const float (&gr)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = k0 * gr[j][0] + k1 * gr[j][2], x1 = k0 * gr[j][1] + k1 * gr[j][3];
+      const float bv[4] = {x0, x0 + x1, x0 - x1, -x1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[q][j], bv[q], acc[q], 0, 0, 0);
+    }
+  };
+  // (gps is even: two groups per iteration, the last iteration re-requests the final group instead of branching)
+  load_group(m0, areg[0], graw[0]);
+  for (int m = m0; m < m1; m += 2) {
+    load_group(m + 1, areg[1], graw[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(areg[0], graw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_group(m + 2 < m1 ? m + 2 : m1 - 1, areg[0], graw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(areg[1], graw[1]);
+  }
+
+  // dW = G^T dU G: over b in the wave (X[kw]), over a across the waves
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float u0 = acc[0][r], u1 = acc[1][r], u2 = acc[2][r], u3 = acc[3][r];
+    wgw_lds[((a * 3 + 0) * 16 + r) * 64 + lane] = u0 + 0.5f * (u1 + u2);
+    wgw_lds[((a * 3 + 1) * 16 + r) * 64 + lane] = 0.5f * (u1 - u2);
+    wgw_lds[((a * 3 + 2) * 16 + r) * 64 + lane] = 0.5f * (u1 + u2) + u3;
+  }
+  __syncthreads();
+  float* yp = prm.y + (long long)p * prm.y_ps;
+  const float* vp = prm.v ? prm.v + (long long)p * prm.v_ps : nullptr;
+  const float sc = prm.scale ? prm.scale[n] : 1.f;
+  for (int o = a; o < 9; o += 4) {
+    const int kh = o / 3, kw = o - 3 * kh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x0 = wgw_lds[((0 * 3 + kw) * 16 + r) * 64 + lane], x1 = wgw_lds[((1 * 3 + kw) * 16 + r) * 64 + lane];
+      const float x2 = wgw_lds[((2 * 3 + kw) * 16 + r) * 64 + lane], x3 = wgw_lds[((3 * 3 + kw) * 16 + r) * 64 + lane];
+      const float w = sc * (kh == 0 ? (x0 + 0.5f * (x1 + x2)) : (kh == 1 ? 0.5f * (x1 - x2) : (0.5f * (x1 + x2) + x3)));
+      const int ci = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const long long idx = ((long long)(o * C + ci)) * N + n;
+      if (prm.S > 1) atomicAdd(yp + idx, w);
+      else if (prm.overwrite) yp[idx] = w + (vp ? prm.alpha * vp[idx] : 0.f);
+      else yp[idx] += w;
+    }
+  }
+}
+
+static int cu_count();
+static float* ksplit_scratch(size_t floats, hipStream_t st);
+int wino_mode();
+
+// shares of the tiles per (probe, c tile, n tile): 1 when the launch fills the chip without splitting
+static int wgrad_wino_splits(const WgradP& p, int P) {
+  const long long blocks = (long long)(p.C / 32) * (p.N / 32) * P;
+  const long long want = 4ll * cu_count();
+  const int groups = (p.R / 4 + 7) / 8;
+  long long S = blocks >= want ? 1 : (want + blocks - 1) / blocks;
+  if (S > groups / 16) S = groups / 16;
+  if (S > 64) S = 64;
+  return (int)(S < 1 ? 1 : S);
+}
+
+static bool wgrad_wino_ok(const WgradP& p, int P) {
+  if (wino_mode() == 0 || precision_mode() != 0 || p.seg_rows > 0) return false;
+  if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return false;
+  if ((p.C & 31) != 0 || (p.N & 31) != 0 || p.M != 9 * p.C) return false;
+  const int OH = p.OHW / p.OW;
+  if (OH != p.IH || p.OW != p.IW || (OH & 1) || (p.OW & 7) != 0) return false;          // TW % 4 == 0
+  if ((long long)p.R * p.N * 4 >= (1ll << 31)) return false;
+  const long long T = p.R / 4;
+  if (16ll * (T + 16ll * 64) * p.C * 4 >= (1ll << 31)) return false;
+  if (wino_mode() == 2) return true;
+  return (long long)(p.C / 32) * (p.N / 32) * P * wgrad_wino_splits(p, P) >= 2ll * cu_count() && T >= 256;
+}
+
+static hipError_t run_wgrad_wino(const WgradP& p, int P, hipStream_t st) {
+  WgWinoP q;
+  const int OH = p.OHW / p.OW, TH = OH / 2, TW = p.OW / 2;
+  const int T = p.R / 4, groups = (T + 7) / 8;
+  const int S = wgrad_wino_splits(p, P);
+  int gps = (groups + S - 1) / S; gps += gps & 1;
+  q.S = S; q.gps = gps; q.TQ = 2 * gps * S; q.T = T; q.TW = TW; q.tpi = TH * TW;
+  q.dTPI = FastDiv((unsigned)q.tpi); q.dTW = FastDiv((unsigned)TW);
+  q.H = OH; q.W = p.OW; q.C = p.C; q.N = p.N;
+  const size_t vfloats = (size_t)16 * q.TQ * p.C * 4;
+  float* vt = ksplit_scratch(vfloats, st);
+  if (!vt) return hipErrorOutOfMemory;
+  q.vt = vt; q.vt_bytes = (unsigned)(vfloats * 4);
+  q.g = p.g; q.g_ps = p.g_ps; q.g_bytes = (unsigned)((long long)p.R * p.N * 4);
+  q.y = p.y; q.y_ps = p.y_ps; q.scale = p.scale;
+  q.overwrite = (p.overwrite && S == 1) ? 1 : 0; q.v = p.v; q.v_ps = p.v_ps; q.alpha = p.alpha;
+  if (p.overwrite && S != 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)(((long long)q.TQ * p.C + 255) / 256)), dim3(256), 0, st, p.a, vt, OH, p.OW, p.C, TH, TW, T, q.TQ);
+  const size_t shmem = 12 * 1024 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)((p.C / 32) * (p.N / 32) * S), (unsigned)P), dim3(256), shmem, st, q);
   return hipGetLastError();
 }
 
@@ -2813,6 +3038,11 @@ hipError_t launch_wgrad(const WgradP& p, int P, hipStream_t st) {
     if (p.R <= 16) return run_wgrad_skinny<2, 8>(p, P, st);
     if (p.R <= 52) return run_wgrad_skinny<2, 26>(p, P, st);
     return run_wgrad_skinny<2, 32>(p, P, st);
+  }
+  if (wgrad_wino_ok(p, P)) {
+    const hipError_t e = run_wgrad_wino(p, P, st);
+    if (e != hipErrorOutOfMemory) return e;             // (no scratch for the transformed activations: the direct kernels)
+    (void)hipGetLastError();
   }
   if (p.overwrite) return hipErrorInvalidValue;       // the engine asks for it only where wgrad_will_overwrite() holds
   static const bool nopb = getenv("LIP_NOPB") != nullptr || getenv("LIP_GENERIC") != nullptr;   // A/B switch
