@@ -300,6 +300,7 @@ def main():
     torch.cuda.synchronize()
     primal_ms = 1e3 * (time.perf_counter() - t1) / 5
     flops = eng.flops_per_probe()
+    xflops = eng.executed_flops_per_probe()        # Winograd ops multiply 4/9 as often as their algorithmic count says
     kinds = {nv.OP_IGEMM: "igemm_kernel", nv.OP_WGRAD: "wgrad_kernel"}
     per_kernel = {}
     for k, name in kinds.items():
@@ -307,15 +308,26 @@ def main():
         if cnt:
             per_kernel[name] = dict(ms_per_step=ms / prof_steps, launches_per_step=cnt // prof_steps,
                                     avg_launch_ms=ms / cnt,
-                                    tflops=flops[k] * P * prof_steps / (ms * 1e-3) / 1e12)
+                                    tflops=flops[k] * P * prof_steps / (ms * 1e-3) / 1e12,
+                                    executed_tflops=xflops[k] * P * prof_steps / (ms * 1e-3) / 1e12,
+                                    mfma_pipe_utilisation=xflops[k] * P * prof_steps / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
     other_ms = sum(ms for k, (ms, c) in prof.items() if k not in kinds) / prof_steps
     dom = "igemm_kernel"
     achieved = per_kernel[dom]["tflops"]
     # HBM bytes per launch are NOT measured inside this run (the PMC passes need rocprofv3 around the process): null here;
     # the committed counter passes of this same command are profiles/r3_traffic.json (scripts/profile.sh)
     traffic = None
-    roofline = dict(bound="mfma", kernel=dom + " (tangent-forward + data-gradient implicit GEMMs, f32 MFMA)",
+    winograd_on = bool(eng.lib.lip_get_winograd() != 0 and eng.lib.lip_get_precision() == 0)
+    roofline = dict(bound="mfma", kernel=dom + " (tangent-forward + data-gradient implicit GEMMs, f32 MFMA"
+                                         + ("; the 3x3 stride-1 layers as Winograd F(2x2,3x3)" if winograd_on else "") + ")",
                     achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_MFMA_TFLOPS,
+                    winograd=winograd_on,
+                    executed=dict(tflops=per_kernel[dom]["executed_tflops"], frac=per_kernel[dom]["mfma_pipe_utilisation"],
+                                  whole_sweep_tflops=sum(xflops.values()) * P / (ms_per_step * 1e-3) / 1e12,
+                                  note="`achieved` / `frac` count ALGORITHMIC FLOPs (SURVEY 8d: 8 MACs_fwd per example-probe) "
+                                       "per second, so with the Winograd route on they can exceed the pipe's peak: those ops "
+                                       "issue 4/9 of their algorithmic multiplications.  `executed` counts the FLOPs the MFMA "
+                                       "instructions actually perform — its `frac` is the utilisation of the f32 matrix pipe"),
                     traffic=traffic, per_kernel=per_kernel, other_kernels_ms_per_step=other_ms,
                     primal_pass_ms=primal_ms, primal_pass_tflops=2 * net.macs_per_example() * n / (primal_ms * 1e-3) / 1e12,
                     whole_sweep_tflops=sum(flops.values()) * P / (ms_per_step * 1e-3) / 1e12,

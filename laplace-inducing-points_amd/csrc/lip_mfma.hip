@@ -1126,6 +1126,7 @@ struct WinoX {
   unsigned a_bytes[3]; unsigned u_bytes[3];
   int BWs, BHs, NI, FR, FC, nbx, nby, NS, n_img, TH, TW;
   float inv_frfc, inv_fc;
+  FastDiv dnb, dbxy, dnbx;              // N / 32, nbx * nby, nbx
 };
 
 // U[xi = 4a + b][c / 4][n][c % 4] = (G w G^T)[a][b] of the 3x3 kernel w[kh][kw][c][n]  (flip: w[2-kh][2-kw])
@@ -1189,10 +1190,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
       }
     }
   }
-  const int tbid = bid / nb, cb = bid - tbid * nb;
+  const int tbid = wx.dnb.div(bid), cb = bid - tbid * nb;
   const int bxy = wx.nbx * wx.nby;
-  const int bi = tbid / bxy, brem = tbid - bi * bxy;
-  const int by = brem / wx.nbx, bx = brem - by * wx.nbx;
+  const int bi = wx.dbxy.div(tbid), brem = tbid - bi * bxy;
+  const int by = wx.dnbx.div(brem), bx = brem - by * wx.nbx;
   const int p = byp;
   const int n0 = cb * BN;
   if (tid < 2 * BN) redbuf[tid] = 0.f;
@@ -2175,6 +2176,7 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* 
     *reinterpret_cast<f32x4v*>(&vt[(((long long)xi * TQ + tq) * C + c) * 4]) = f32x4v{v[xi][0], v[xi][1], v[xi][2], v[xi][3]};
 }
 
+template <bool ROWQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_wino_kernel(const WgWinoP prm) {
   extern __shared__ __attribute__((aligned(16))) float wgw_lds[];          // [4 a][3 kw][16 reg][64 lane]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2223,16 +2225,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       ar[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(vrs, avoff, (4 * a + q) * a_xi + (unsigned)(2 * m) * C * 16, 0));
-    const int t = 8 * m + 4 * h;                      // (TW % 4 == 0: the lane's four tiles share a tile row)
-    const int img = prm.dTPI.div(t), rem = t - img * prm.tpi, ty = prm.dTW.div(rem), tx = rem - ty * prm.TW;
-    const unsigned gv = t < prm.T ? (unsigned)((((img * H + 2 * ty) * W + 2 * tx) * N + n) * 4) : 0x80000000u;
+    const int t = 8 * m + 4 * h;
+    if (ROWQ) {                                       // TW % 4 == 0: the lane's four tiles share a tile row
+      const int img = prm.dTPI.div(t), rem = t - img * prm.tpi, ty = prm.dTW.div(rem), tx = rem - ty * prm.TW;
+      const unsigned gv = t < prm.T ? (unsigned)((((img * H + 2 * ty) * W + 2 * tx) * N + n) * 4) : 0x80000000u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          gr[j][2 * r + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gv + (unsigned)((2 * j + q) * N * 4), r * row_bytes, 0));
+          for (int q = 0; q < 2; ++q)
+            gr[j][2 * r + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gv + (unsigned)((2 * j + q) * N * 4), r * row_bytes, 0));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tj = t + j;
+        const int img = prm.dTPI.div(tj), rem = tj - img * prm.tpi, ty = prm.dTW.div(rem), tx = rem - ty * prm.TW;
+        const unsigned gv = tj < prm.T ? (unsigned)((((img * H + 2 * ty) * W + 2 * tx) * N + n) * 4) : 0x80000000u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            gr[j][2 * r + q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, gv + (unsigned)(q * N * 4), r * row_bytes, 0));
+      }
+    }
   };
   auto compute = [&](const f32x4v (&ar)[4], const float (&gr)[4][4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -2303,7 +2319,7 @@ static bool wgrad_wino_ok(const WgradP& p, int P) {
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return false;
   if ((p.C & 31) != 0 || (p.N & 31) != 0 || p.M != 9 * p.C) return false;
   const int OH = p.OHW / p.OW;
-  if (OH != p.IH || p.OW != p.IW || (OH & 1) || (p.OW & 7) != 0) return false;          // TW % 4 == 0
+  if (OH != p.IH || p.OW != p.IW || (OH & 1) || (p.OW & 1) != 0) return false;
   if ((long long)p.R * p.N * 4 >= (1ll << 31)) return false;
   const long long T = p.R / 4;
   if (16ll * (T + 16ll * 64) * p.C * 4 >= (1ll << 31)) return false;
@@ -2332,11 +2348,14 @@ static hipError_t run_wgrad_wino(const WgradP& p, int P, hipStream_t st) {
   const size_t shmem = 12 * 1024 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)((p.C / 32) * (p.N / 32) * S), (unsigned)P), dim3(256), shmem, st, q);
+  const dim3 grid((unsigned)((p.C / 32) * (p.N / 32) * S), (unsigned)P);
+  if ((TW & 3) == 0) hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(256), shmem, st, q);
+  else hipLaunchKernelGGL(wgrad_wino_kernel<false>, grid, dim3(256), shmem, st, q);
   return hipGetLastError();
 }
 
@@ -2894,6 +2913,7 @@ static hipError_t run_igemm_wino(const IgemmP& p, int P, hipStream_t st) {
   wx.BWs = g.BWs; wx.BHs = g.BHs; wx.NI = g.NI; wx.FR = g.FR; wx.FC = g.FC; wx.nbx = g.nbx; wx.nby = g.nby; wx.NS = g.NS;
   wx.n_img = (int)n_img; wx.TH = g.TH; wx.TW = g.TW;
   wx.inv_frfc = 1.f / (float)(g.FR * g.FC); wx.inv_fc = 1.f / (float)g.FC;
+  wx.dnb = FastDiv((unsigned)(p.N / 32)); wx.dbxy = FastDiv((unsigned)(g.nbx * g.nby)); wx.dnbx = FastDiv((unsigned)g.nbx);
   q.zeros = nullptr; q.dbg = nullptr; q.partial = nullptr;
   const size_t shmem = (size_t)(8192 + 32 + 64) * sizeof(float);
   static bool attr_set = false;

@@ -511,6 +511,39 @@ def tape_flops_per_probe(cn: CompiledNet):
     return out
 
 
+def tape_executed_flops_per_probe(cn: CompiledNet):
+    """Matrix-pipe FLOPs the kernels EXECUTE for one probe's sweep when the Winograd route is on: the ops that
+    csrc/lip_mfma.hip sends to igemm_wino_kernel / wgrad_wino_kernel (3x3, stride 1, pad 1, channel counts multiples
+    of 32, even maps) multiply 16 times per 2x2 output patch and (c, n)
+    instead of 36 — 4/9 of the algorithmic count (padded tile blocks not counted); every other op executes its
+    algorithmic FLOPs.  The utilisation of the f32 MFMA pipe follows from THIS count; `tape_flops_per_probe` stays the
+    algorithmic figure the throughput is quoted in."""
+    out = {}
+    for which in (1, 2):
+        for op in cn.tapes[which]:
+            R = op.n_img * op.OH * op.OW
+            even = op.OH % 2 == 0 and op.OW % 2 == 0
+            if op.kind == nv.OP_IGEMM:
+                segs = [op.seg[i] for i in range(op.nseg)]
+                wino = (even and op.N % 32 == 0 and op.N >= 32 and
+                        all(sg.KH == 3 and sg.KW == 3 and sg.stride == 1 and sg.pad_h == 1 and sg.pad_w == 1 and
+                            sg.C % 32 == 0 and sg.IH == op.OH and sg.IW == op.OW for sg in segs))
+                fl = 0
+                for sg in segs:
+                    if sg.mode == 0:
+                        fl += 2 * R * op.N * sg.KH * sg.KW * sg.C
+                    else:
+                        fl += 2 * op.n_img * sg.IH * sg.IW * sg.C * sg.KH * sg.KW * op.N
+                out[nv.OP_IGEMM] = out.get(nv.OP_IGEMM, 0) + (fl * 4 // 9 if wino else fl)
+            elif op.kind == nv.OP_WGRAD:
+                sg = op.seg[0]
+                wino = (even and op.N % 32 == 0 and sg.C % 32 == 0 and sg.KH == 3 and sg.KW == 3 and
+                        sg.stride == 1 and sg.pad_h == 1 and sg.pad_w == 1 and sg.IH == op.OH and sg.IW == op.OW)
+                fl = 2 * R * op.N * op.M
+                out[nv.OP_WGRAD] = out.get(nv.OP_WGRAD, 0) + (fl * 4 // 9 if wino else fl)
+    return out
+
+
 class LinearizedNet:
     """The linearised-network operator bound to (network, theta_MAP, data slice Z) on one GPU.
 
@@ -609,6 +642,13 @@ class LinearizedNet:
 
     def flops_per_probe(self):
         return tape_flops_per_probe(self.cn)
+
+    def executed_flops_per_probe(self):
+        """matrix-pipe FLOPs actually issued per probe (Winograd ops at 4/9 of their algorithmic count) when the route
+        is on (``lip_get_winograd() != 0``), else the algorithmic count"""
+        if self.lib.lip_get_winograd() == 0 or self.lib.lip_get_precision() != 0:
+            return tape_flops_per_probe(self.cn)
+        return tape_executed_flops_per_probe(self.cn)
 
     # ------------------------------------------------------------------------------ operators
     def ggn_vp(self, V: torch.Tensor, scale: float = 1.0, alpha: float = 0.0, out: Optional[torch.Tensor] = None):

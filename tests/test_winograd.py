@@ -13,7 +13,7 @@ def _binding(n, hw=32, seed=3):
     from lip_amd.engine import LinearizedNet
     from lip_amd.scalemodels import ResNet1M
     from lip_amd.toymodels import create_state
-    net = ResNet1M(10)
+    net = ResNet1M(10, input_shape=(hw, hw, 3))
     st = create_state(net, seed=seed, dtype=torch.float32)
     Z = torch.rand(n, hw, hw, 3, generator=torch.Generator().manual_seed(5)).cuda()
     return st, Z, LinearizedNet(st, Z, "classifier", workspace_bytes=1 << 30, max_chunk=8)
@@ -71,6 +71,28 @@ def test_winograd_against_the_float64_oracle():
     err_direct = ((y_direct - ref).abs().max() / ref.abs().max()).item()
     assert err < 2e-4, (err, err_direct)
     assert err <= max(10.0 * err_direct, 2e-5), (err, err_direct)
+
+
+@pytest.mark.parametrize("hw", [28, 24])
+def test_ragged_tile_blocks_and_tile_rows(hw):
+    """maps whose tile grid is not a multiple of the block rectangle (14 x 14, 7 x 7, 12 x 12, 6 x 6, 3 x 3 tiles): masked
+    tiles of the implicit GEMM, the per-tile coordinate path of the weight gradient (tile rows not a multiple of 4 tiles
+    wide); 7 x 7 maps (hw = 28) are ineligible and fall through to the direct kernels"""
+    from lip_amd import _native as nv, krylov
+    lib = nv.load()
+    st, Z, eng = _binding(3, hw=hw)
+    V = krylov.fill_rademacher(3, eng.D, 13, "cuda")
+    before = lib.lip_get_winograd()
+    try:
+        lib.lip_set_winograd(0)
+        y_off = eng.ggn_vp(V, 1.0, 0.5).clone()
+        lib.lip_set_winograd(2)
+        y_on = eng.ggn_vp(V, 1.0, 0.5).clone()
+    finally:
+        lib.lip_set_winograd(before)
+    err = (y_on - y_off).abs().max().item() / y_off.abs().max().item()
+    assert err <= 2e-5, err
+    assert not torch.equal(y_on, y_off)
 
 
 def test_the_primal_tape_never_takes_the_route():
