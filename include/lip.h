@@ -125,9 +125,9 @@ int lip_get_precision(void);
 int lip_set_split_k(int32_t on);
 /* Winograd F(2x2, 3x3) route of the 3x3 / stride-1 / pad-1 layers of the tangent and backward tapes (2.25x fewer
  * matrix-pipe multiplications, f32 in / f32 accumulate; the transforms move a layer's result by ~2e-7 relative;
- * DESIGN.md section 4): 0 = off (the direct implicit GEMMs everywhere), 1 = auto (default: launches that fill the
- * chip), 2 = every eligible launch (tests).  Never applied to the primal tape.  The environment variables
- * LIP_NOWINO / LIP_WINO=force are read once; this call overrides them.                                  */
+ * DESIGN.md section 4): 0 = off (the direct implicit GEMMs everywhere), 1 = on (default: every eligible launch),
+ * 2 = on (the value the tests set; the same launches as 1).  Never applied to the primal tape.  The environment
+ * variable LIP_NOWINO is read once; this call overrides it.                                             */
 int lip_set_winograd(int32_t mode);
 int lip_get_winograd(void);
 

@@ -147,3 +147,21 @@ def ptr(t) -> int:
 def stream_ptr() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def winograd_route(mode: int):
+    """Process-wide switch of the Winograd route (``lip_set_winograd``) for the duration of a block; restores the
+    previous setting.  0 = the direct implicit GEMMs everywhere: bit-for-bit fmaf chains, and an absolute rounding error
+    ~4x smaller than the Winograd transforms' on products whose result cancels to far below ||A|| ||v|| (the deflated
+    Krylov routes work exactly there); 1 / 2 = the route on."""
+    lib = load()
+    before = lib.lip_get_winograd()
+    check(lib.lip_set_winograd(int(mode)), "lip_set_winograd")
+    try:
+        yield
+    finally:
+        lib.lip_set_winograd(before)

@@ -515,8 +515,17 @@ class RangeDeflation:
         return out
 
     def wrap(self, matvec: Callable) -> Callable:
-        """the operator restricted to the complement: v -> P_perp A v (for v already in the complement)"""
-        return lambda V: self.project_out(matvec(V), passes=2)
+        """the operator restricted to the complement: v -> P_perp A v (for v already in the complement).  The product
+        runs on the DIRECT implicit GEMMs (Winograd route off for the call): on the complement A v cancels to
+        alpha v ~ 1e-9 ||A|| ||v||, the recurrences stop at the product's absolute rounding error, and the direct
+        kernels' is ~4x smaller than the Winograd transforms' (deflated CG at the config's alpha: 2 iterations against
+        9 for the same answer, tests/test_sampler_fullsize.py); at the 8 - 16 right-hand sides of these solves the
+        route is worth 10 % of a product."""
+        def complement_product(V):
+            with nv.winograd_route(0):
+                AV = matvec(V)
+            return self.project_out(AV, passes=2)
+        return complement_product
 
     def relative_residual(self, A: Callable, X: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
         """||A x - b|| / ||b|| per row, evaluated in the two invariant subspaces: lam_k <q_k, x> - <q_k, b> on range(Q)
@@ -524,7 +533,9 @@ class RangeDeflation:
         residual of an accurate solution is swamped by the same range(W) noise the deflation removes
         (eps ||A|| ||x|| ~ 300 ||b|| at alpha = 0.005)."""
         rr = self.coeffs(X) * self.lam[None, :] - self.coeffs(B)
-        rp = self.project_out(A(X), passes=2) - self.project_out(B)
+        with nv.winograd_route(0):                   # (as in :meth:`wrap`)
+            AX = A(X)
+        rp = self.project_out(AX, passes=2) - self.project_out(B)
         return torch.sqrt((rr * rr).sum(1) + (rp.double() ** 2).sum(1)) / B.double().norm(dim=1)
 
     def closed_form(self, B: torch.Tensor, f: Callable, lam_perp: float) -> torch.Tensor:

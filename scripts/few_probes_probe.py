@@ -9,7 +9,7 @@ from lip_amd.toymodels import create_state
 
 net = ResNet1M(10); st = create_state(net, seed=1, dtype=torch.float32)
 eng = LinearizedNet(st, torch.rand(50, 32, 32, 3).cuda(), "classifier", workspace_bytes=4 << 30, max_chunk=16)
-for P in (1, 2, 4, 8):
+for P in (1, 2, 4, 8, 16, 32):
     V = krylov.fill_rademacher(P, eng.D, 1, "cuda")
     out = torch.empty_like(V)
     for _ in range(5):

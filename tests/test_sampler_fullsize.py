@@ -77,12 +77,26 @@ def test_eigh_sampler_against_matrix_free_operator(setup):
     lam_k = (1.0 / (pt.g[rows] + 1.0 / math.sqrt(ALPHA))) ** 2          # alpha + beta lambda_k
     AQ = s["A"](Qk).double()
     m["eigpair_residual"] = ((AQ - lam_k[:, None] * Qk.double()).norm(dim=1) / lam_k).max().item()
+    # the same residual through the DIRECT implicit GEMMs (Winograd route off): A q_k is ~1e-4 ||A|| ||q_k|| here, so the
+    # residual is the operator's absolute rounding error magnified by ||A|| / lambda_k; the Winograd transforms carry a
+    # larger constant in exactly that error (2e-7 of a random product's scale, scripts/winograd_accuracy.py — 4x on this
+    # cancelling one)
+    from lip_amd import _native as nv
+    lib = nv.load()
+    before = lib.lip_get_winograd()
+    try:
+        lib.lip_set_winograd(0)
+        AQd = s["A"](Qk).double()
+    finally:
+        lib.lip_set_winograd(before)
+    m["eigpair_residual_direct_route"] = ((AQd - lam_k[:, None] * Qk.double()).norm(dim=1) / lam_k).max().item()
     cx, cv = X.double() @ Qk.double().T, s["V"].double() @ Qk.double().T          # (S, 9)
     m["stiff_direction_error"] = ((cx * lam_k.sqrt() - cv).abs() / cv.abs().clamp_min(0.1)).max().item()
     m["lam_checked"] = lam_k.tolist()
     print("SAMPLER_FULLSIZE eigh " + json.dumps(m))
     eps = 2.0 ** -24
-    assert m["eigpair_residual"] <= 5e-4          # measured 7e-5 .. 1.6e-4 over boxes (the weakest kept direction sets it)
+    assert m["eigpair_residual_direct_route"] <= 5e-4   # measured 7e-5 .. 1.6e-4 over boxes (the weakest kept direction sets it)
+    assert m["eigpair_residual"] <= 2e-3                # default route (Winograd on): measured 6.3e-4
     # floor: eps * sqrt(cond) = 3.3e-3 of a unit coefficient; coefficients down to 0.1 units are in the maximum
     assert m["stiff_direction_error"] <= 5e-2
     # whitening: float32 factor rows and two float32 GEMM passes over D = 1.08 M; A^(1/2)-weighted error per draw is
@@ -171,4 +185,8 @@ def test_deflated_cg_solves_the_config_system(setup):
     errp = ((Xp - Xref).norm(dim=1) / Xref.norm(dim=1)).max().item()
     print(f"SAMPLER_FULLSIZE cg alpha={ALPHA}: deflated {info['iterations']} iterations forward error {err:.3e} (subspace residual "
           f"{res:.3e}); plain {infop['iterations']} iterations forward error {errp:.3e}")
-    assert info["iterations"] <= 4 and err <= 1.5e-2 and errp > 0.5        # measured 2 iterations, <= 4.4e-3; plain 0.74
+    # measured: 2 iterations, <= 4.4e-3 (round 3, direct kernels everywhere); 5 iterations, 9.5e-4 since the factor behind
+    # the deflation basis is built with the Winograd route on (the complement products themselves run the direct route,
+    # RangeDeflation.wrap; with them on the Winograd route too: 9 iterations, 1.6e-3); plain CG 0.74.  The count at the
+    # noise floor is decided by rounding (docstring) — the forward error is the assertion that matters
+    assert info["iterations"] <= 10 and err <= 1.5e-2 and errp > 0.5
