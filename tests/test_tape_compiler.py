@@ -72,6 +72,21 @@ def test_resnet1m_layout_matches_survey():
     fl = sum(tape_flops_per_probe(cn).values())
     first = 32 * 32 * 27 * 32
     assert fl == 50 * (8 * 162_366_720 - 4 * first)
+    # executed matrix-pipe FLOPs with the Winograd route on (bench.py's roofline.executed): the 3x3 / stride-1 / pad-1
+    # layers with 32 | C and 32 | N — 18 of the net's 3x3 convolutions: 6 per stage (stage 1: both convs of its three
+    # blocks; stages 2, 3: all but the stride-2 first conv, i.e. 5) ... counted from the net itself — at 4/9, the rest as is
+    from lip_amd.engine import tape_executed_flops_per_probe
+    ex = sum(tape_executed_flops_per_probe(cn).values())
+    macs_wino = 0
+    for u in net.units:
+        if u.kind == "conv" and u.kh == 3 and u.kw == 3 and u.stride == 1 and u.cin % 32 == 0 and u.cout % 32 == 0:
+            oh, ow, _ = net.tensors[u.dst]
+            macs_wino += oh * ow * 9 * u.cin * u.cout
+    assert macs_wino > 0.9 * (162_366_720 - 2 * first)          # ~95 % of the forward MACs
+    # every eligible layer contributes 8 MACs-worth of algorithmic FLOPs (4 tangent + 2 data gradient + 2 weight
+    # gradient), all of them on the route
+    assert ex == fl - 50 * (8 * macs_wino - (8 * macs_wino) * 4 // 9) or abs(ex - (fl - 50 * 8 * macs_wino * 5 / 9)) <= 64
+    assert 0.45 < ex / fl < 0.50
 
 
 def test_resnet50_parameter_count():
