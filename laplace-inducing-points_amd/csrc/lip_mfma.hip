@@ -1162,8 +1162,113 @@ __global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float*
   }
 }
 
+// Fused epilogue of the Winograd kernel with 16-byte accesses (same arithmetic and operand meaning as igemm_epilogue):
+// after the cross-wave exchange a wave owns pixel (po, qo) of the block's 32 tiles x 32 columns; lane (ti = lane >> 3,
+// cq = lane & 7) takes columns 4 cq .. 4 cq + 3 of tiles ti, ti + 8, ti + 16, ti + 24 — four consecutive columns of one
+// tile are four consecutive floats of the exchange area ([a][q][reg][lane], lane = column) and of every operand tensor,
+// so the three exchange reads, the operand loads and the store of a tile are one ds_read_b128 / dwordx4 each (20 memory
+// instructions per lane where the accumulator-layout epilogue issues 80).  Used when every operand is 16-byte aligned.
+__device__ __forceinline__ void wino_epilogue_v4(const IgemmP& prm, const float* xch, float* redbuf, const int* rowtab, int p, int n0,
+                                                 int lane, int tid, int a, bool blk_full) {
+  const int po = a >> 1, qo = a & 1;
+  const int cq = lane & 7, ti = lane >> 3;
+  const int N = prm.N;
+  const int col = n0 + 4 * cq;
+  const int shift = po * prm.OW + qo;
+  const bool has_e1 = prm.e1 != nullptr, has_r1 = prm.red1 != nullptr;
+  const bool do_red = (prm.red0 != nullptr) || (prm.red1 != nullptr);
+  const float* __restrict__ res = prm.res ? prm.res + (long long)p * prm.res_ps : nullptr;
+  float* __restrict__ out = prm.out + (long long)p * prm.out_ps;
+  float sc[4], e0v[4], e1v[4], s0[4], s1[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    sc[c] = prm.scale ? prm.scale[col + c] : 1.f;
+    e0v[c] = prm.e0 ? prm.e0[(long long)p * prm.e0_ps + col + c] : 0.f;
+    e1v[c] = has_e1 ? prm.e1[(long long)p * prm.e1_ps + col + c] : 0.f;
+    s0[c] = 0.f; s1[c] = 0.f;
+  }
+  f32x4v y[4], xv[4], rv[4], dv[4], x2[4];
+  unsigned idx[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = ti + 8 * k;
+    const int base = ((i & 3) + 4 * (i >> 3)) * 64 + ((i >> 2) & 1) * 32 + 4 * cq;      // accumulator row i, columns 4 cq ..
+    const f32x4v t1 = *reinterpret_cast<const f32x4v*>(&xch[(1 * 2 + qo) * 1024 + base]);
+    const f32x4v t2 = *reinterpret_cast<const f32x4v*>(&xch[(2 * 2 + qo) * 1024 + base]);
+    const f32x4v t03 = *reinterpret_cast<const f32x4v*>(&xch[((po ? 3 : 0) * 2 + qo) * 1024 + base]);
+    y[k] = po ? (t1 - t2 - t03) : (t03 + t1 + t2);
+    const int rt = rowtab[i];
+    ok[k] = rt >= 0;
+    idx[k] = ok[k] ? (unsigned)((rt + shift) * N + col) : 0u;                             // clamped: loads stay unconditional
+  }
+  const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+  if (has_e1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const f32x4v*>(prm.xhat + idx[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = zero4;
+  }
+  if (res) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rv[k] = *reinterpret_cast<const f32x4v*>(res + idx[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rv[k] = zero4;
+  }
+  if (prm.dphi) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dv[k] = *reinterpret_cast<const f32x4v*>(prm.dphi + idx[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dv[k] = one4;
+  }
+  if (has_r1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x2[k] = *reinterpret_cast<const f32x4v*>(prm.xhat2 + idx[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x2[k] = zero4;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x4v v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (y[k][c] * sc[c] + e0v[c] + e1v[c] * xv[k][c] + rv[k][c]) * dv[k][c];
+    if (blk_full || ok[k]) {
+      *reinterpret_cast<f32x4v*>(out + idx[k]) = v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { s0[c] += v[c]; s1[c] += v[c] * x2[k][c]; }
+    }
+  }
+  if (do_red) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int off = 8; off < 64; off <<= 1) {
+        s0[c] += __shfl_xor(s0[c], off, 64);
+        s1[c] += __shfl_xor(s1[c], off, 64);
+      }
+    }
+    if (ti == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        atomicAdd(&redbuf[4 * cq + c], s0[c]);
+        atomicAdd(&redbuf[32 + 4 * cq + c], s1[c]);
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      if (prm.red0) atomicAdd(prm.red0 + (long long)p * prm.red0_ps + n0 + tid, redbuf[tid]);
+      if (prm.red1) atomicAdd(prm.red1 + (long long)p * prm.red1_ps + n0 + tid, redbuf[32 + tid]);
+    }
+  }
+}
+
 constexpr int WINO_SLOTS = 224;     // LDS pixel slots of the staged footprint (9 x 16 bytes each)
 
+template <bool VEPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void igemm_wino_kernel(const IgemmP prm, const WinoX wx) {
   // stage [WINO_SLOTS][36] floats, later the exchange [4 a][2 q][16 reg][64 lane] (aliased); then rowtab[32], redbuf[64]
   extern __shared__ __attribute__((aligned(16))) float wino_lds[];
@@ -1323,6 +1428,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void i
   }
   __syncthreads();
   // ... and across the waves over a: wave w owns output pixel (po, qo) of every tile
+  if (VEPI) {
+    wino_epilogue_v4(prm, wino_lds, redbuf, rowtab, p, n0, lane, tid, a, blk_full);
+    return;
+  }
   const int po = a >> 1, qo = a & 1;
   f32x16 y[1][1];
 #pragma unroll
@@ -2920,12 +3029,18 @@ static hipError_t run_igemm_wino(const IgemmP& p, int P, hipStream_t st) {
   const size_t shmem = (size_t)(8192 + 32 + 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)igemm_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)igemm_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)igemm_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  // 16-byte epilogue accesses when every operand tensor allows them (A/B switch LIP_WINO_NOVEPI)
+  auto al16 = [](const void* ptr, long long ps) { return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && (ps & 3) == 0); };
+  static const bool novepi = getenv("LIP_WINO_NOVEPI") != nullptr;
+  const bool vepi = !novepi && al16(p.out, p.out_ps) && al16(p.res, p.res_ps) && al16(p.xhat, 0) && al16(p.dphi, 0) && al16(p.xhat2, 0);
   dim3 grid((unsigned)((long long)g.nbx * g.nby * g.nbi * (p.N / 32)), (unsigned)P, 1);
-  hipLaunchKernelGGL(igemm_wino_kernel, grid, dim3(256), shmem, st, q, wx);
+  if (vepi) hipLaunchKernelGGL(igemm_wino_kernel<true>, grid, dim3(256), shmem, st, q, wx);
+  else hipLaunchKernelGGL(igemm_wino_kernel<false>, grid, dim3(256), shmem, st, q, wx);
   return hipGetLastError();
 }
 
