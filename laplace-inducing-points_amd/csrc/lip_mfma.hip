@@ -2439,9 +2439,14 @@ static bool wgrad_wino_ok(const WgradP& p, int P) {
   const int OH = p.OHW / p.OW;
   if (OH != p.IH || p.OW != p.IW || (OH & 1) || (p.OW & 1) != 0) return false;
   if ((long long)p.R * p.N * 4 >= (1ll << 31)) return false;
+  {   // ONE (probe, c tile, n tile) block (a single product on the 32-channel stage): its 12 800 tiles would be split 64 ways
+    // and added with 64-fold contended float atomics — the direct kernel's own row split is faster there (47 vs 31 us;
+    // single product 1.82 -> 1.77 ms).  Two blocks already favour this kernel (2.17 vs 2.60 ms for two products).
+    static const int minb = getenv("LIP_WGW_MINBLOCKS") ? atoi(getenv("LIP_WGW_MINBLOCKS")) : 2;     // A/B switch
+    if ((long long)(p.C / 32) * (p.N / 32) * P < minb) return false;
+  }
   const long long T = p.R / 4;
   if (16ll * (T + 16ll * 64) * p.C * 4 >= (1ll << 31)) return false;
-  (void)P;
   return true;
 }
 
